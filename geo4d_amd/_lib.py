@@ -1,0 +1,117 @@
+"""ctypes binding of libgeo4d_hip.so (include/geo4d_hip.h).
+
+The library is the product: there is NO fallback. If the shared object is missing or an entry point is absent the
+import of any compute path raises immediately (``Geo4DNativeError``) instead of silently running something else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
+ABI_VERSION = 1
+
+F32, BF16, F16 = 0, 1, 2
+
+
+class Geo4DNativeError(RuntimeError):
+    pass
+
+
+class ConvGemm(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("O", C.c_void_p),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("R", C.c_void_p),
+        ("lda", C.c_long), ("ldw", C.c_long), ("ldo", C.c_long), ("ldr", C.c_long),
+        ("a_bs", C.c_long), ("w_bs", C.c_long), ("o_bs", C.c_long), ("r_bs", C.c_long),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
+        ("Cin", C.c_int),
+        ("T", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+        ("KT", C.c_int), ("KH", C.c_int), ("KW", C.c_int), ("pt", C.c_int), ("ph", C.c_int), ("pw", C.c_int),
+        ("stride", C.c_int), ("ups", C.c_int),
+        ("rowbias_div", C.c_int), ("bias_per_row", C.c_int), ("act", C.c_int),
+        ("dtype", C.c_int), ("out_dtype", C.c_int), ("out_nchw", C.c_int), ("tile_hint", C.c_int),
+        ("alpha", C.c_float),
+    ]
+
+
+class GroupNorm(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("ldx", C.c_long), ("ldy", C.c_long),
+        ("F", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("frames_per_stat", C.c_int),
+        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float),
+    ]
+
+
+class Attention(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("o", C.c_void_p),
+        ("k", C.c_void_p * 2), ("v", C.c_void_p * 2),
+        ("ldq", C.c_long), ("ldo", C.c_long), ("ldk", C.c_long * 2), ("ldv", C.c_long * 2),
+        ("Nk", C.c_int * 2), ("kv_div", C.c_int * 2),
+        ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("nseg", C.c_int), ("head_dim", C.c_int), ("dtype", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); this table is checked against include/geo4d_hip.h by tests/test_abi.py
+SIGNATURES = {
+    "geo4d_conv_gemm": (C.c_int, [C.POINTER(ConvGemm), C.c_void_p]),
+    "geo4d_groupnorm_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "geo4d_groupnorm": (C.c_int, [C.POINTER(GroupNorm), C.c_void_p]),
+    "geo4d_layernorm": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_void_p]),
+    "geo4d_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_int,
+                                     C.c_void_p]),
+    "geo4d_attention": (C.c_int, [C.POINTER(Attention), C.c_void_p]),
+    "geo4d_temporal_attention": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
+                                           C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                           C.c_void_p]),
+    "geo4d_tokens_from_ncthw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p]),
+    "geo4d_concat_channels": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long,
+                                        C.c_long, C.c_int, C.c_void_p]),
+    "geo4d_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "geo4d_linear_small": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long,
+                                     C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "geo4d_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
+                                  C.c_void_p]),
+    "geo4d_advance_index": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "geo4d_last_error": (C.c_char_p, []),
+    "geo4d_abi_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object once; raise Geo4DNativeError (never fall back) when it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Geo4DNativeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` (or `make`). "
+            "geo4d_amd has no CPU/PyTorch fallback for its compute path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise Geo4DNativeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise Geo4DNativeError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.geo4d_abi_version() != ABI_VERSION:
+        raise Geo4DNativeError(f"ABI mismatch: library {lib.geo4d_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().geo4d_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

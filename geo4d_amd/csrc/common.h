@@ -1,0 +1,169 @@
+// geo4d_amd/csrc/common.h — shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Everything here is written for ONE target: wave64, MFMA 32x32 tiles, 16-byte LDS/global
+// accesses. There is no other backend and no portability layer.
+//
+// Central abstraction: the "16-byte k-chunk". Every MFMA operand (A or B) is fed per lane as one
+// 16-byte chunk holding EPC = 16/sizeof(T) consecutive K elements of one row:
+//   * 16-bit types (bf16/f16): EPC = 8  -> one v_mfma_f32_32x32x16_{bf16,f16}; lane (i = lane&31,
+//     g = lane>>5) supplies K elements [8g, 8g+8) of row i.
+//   * f32: EPC = 4 -> four v_mfma_f32_32x32x2_f32; MFMA j pairs element j of the A chunk with element
+//     j of the B chunk (the two half-waves g = 0/1 cover two different k). Any bijection of k is legal
+//     for a dot product as long as A and B use the same one, so a chunk-pair always contributes the
+//     products of its EPC * 2 k-values.
+// One cmma() therefore covers K = 2*EPC elements (16 for bf16/f16, 8 for f32) and the callers
+// are dtype-agnostic: bf16 (bench), f16 and exact-f32 (parity mode) share one kernel source.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GEO4D_F32 0
+#define GEO4D_BF16 1
+#define GEO4D_F16 2
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+struct bf16_t { unsigned short v; };
+struct f16_t { unsigned short v; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned int)b) << 16);
+}
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    const unsigned int u = __float_as_uint(f);
+    const unsigned int r = u + 0x7fffu + ((u >> 16) & 1u);
+    const unsigned int q = u | 0x00400000u;  // quiet NaN, payload kept (select, not a branch)
+    return (unsigned short)((((u & 0x7fffffffu) > 0x7f800000u) ? q : r) >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+}
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
+    return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int EPC = 4;      // elements per 16-byte chunk
+    static constexpr int DT = GEO4D_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = GEO4D_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { p->v = f32_to_bf16_bits(v); }
+};
+template <> struct Elem<f16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = GEO4D_F16;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return f16_bits_to_f32(p->v); }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f32_to_f16_bits(v); }
+};
+
+// ---- chunk <-> float conversion -----------------------------------------------------------
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const u32x4& c, float* out);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const u32x4& c, float* out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = __uint_as_float(c[j]);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const u32x4& c, float* out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        out[2 * j] = __uint_as_float(c[j] << 16);
+        out[2 * j + 1] = __uint_as_float(c[j] & 0xffff0000u);
+    }
+}
+template <> __device__ __forceinline__ void chunk_to_f32<f16_t>(const u32x4& c, float* out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        out[2 * j] = f16_bits_to_f32((unsigned short)(c[j] & 0xffffu));
+        out[2 * j + 1] = f16_bits_to_f32((unsigned short)(c[j] >> 16));
+    }
+}
+template <typename T> __device__ __forceinline__ u32x4 f32_to_chunk(const float* in);
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<float>(const float* in) {
+    u32x4 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = __float_as_uint(in[j]);
+    return c;
+}
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<bf16_t>(const float* in) {
+    u32x4 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c[j] = (unsigned int)f32_to_bf16_bits(in[2 * j]) | ((unsigned int)f32_to_bf16_bits(in[2 * j + 1]) << 16);
+    return c;
+}
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<f16_t>(const float* in) {
+    u32x4 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c[j] = (unsigned int)f32_to_f16_bits(in[2 * j]) | ((unsigned int)f32_to_f16_bits(in[2 * j + 1]) << 16);
+    return c;
+}
+
+// ---- chunk-MMA: acc(32x32) += A-chunk x B-chunk -------------------------------------------
+// C/D layout of every 32x32 MFMA on gfx950: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <typename T> __device__ __forceinline__ void cmma(f32x16& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void cmma<bf16_t>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void cmma<f16_t>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void cmma<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+}
+// row index inside a 32x32 accumulator block for register r on half-wave hi
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---- misc ---------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id (8 XCDs, block b lands on XCD b % 8):
+// gives every XCD a contiguous range of logical tiles so neighbouring tiles share its private L2.
+__device__ __forceinline__ long xcd_remap(long bid, long nwg) {
+    const long q = nwg >> 3, r = nwg & 7;
+    const long xcd = bid & 7, idx = bid >> 3;
+    const long base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// host-side error codes (errno-style, negative)
+#define GEO4D_OK 0
+#define GEO4D_EINVAL (-22)
+#define GEO4D_ENOTSUP (-95)
+#define GEO4D_EIO (-5)
+
+#define GEO4D_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) { geo4d_set_error(hipGetErrorString(e__)); return GEO4D_EIO; } \
+    } while (0)
+
+void geo4d_set_error(const char* msg);

@@ -1,0 +1,340 @@
+// geo4d_amd/csrc/norm.hip — HBM-bound normalisation kernels:
+//   GroupNorm(32) [+SiLU] over channels-last tokens, both flavours used by the reference:
+//     * per-frame 4-D   (basics.py:76-87 GroupNormSpecific in ResBlock / `out`; attention.py:265 SpatialTransformer;
+//                         ae_modules.py:15-16 VAE Normalize)            -> frames_per_stat = 1
+//     * across-time 5-D  (openaimodel3d.py:256-266 TemporalConvBlock; attention.py:331,368 TemporalTransformer)
+//                                                                        -> frames_per_stat = T
+//   LayerNorm over C     (attention.py:225-227 BasicTransformerBlock norm1/2/3)
+//   row softmax          (ae_modules.py:66-68 VAE AttnBlock, scores kept in fp32)
+// Statistics are always fp32 (partials merged with Chan's formula in fp64), activations are read and written
+// as 16-byte chunks (8 x bf16/f16 or 4 x f32 per lane) — cdna_hip_programming.md G13.
+// All reductions are order-deterministic (no atomics): the same input gives bit-identical output.
+#include "common.h"
+#include "geo4d_hip.h"
+
+namespace {
+
+__host__ __device__ inline int gn_rows_per_chunk(int HW) {
+    int r = HW / 64;
+    if (r < 32) r = 32;
+    if (r > 1024) r = 1024;
+    return r;
+}
+
+// ---- GroupNorm pass 1: per (frame, row-chunk, group) partial (n, mean, M2) ----------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, long ldx, int HW, int C, int G,
+                                                         int R, int nchunk, float* __restrict__ part) {
+    constexpr int EPC = Elem<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* stage = (float*)smem;               // [256][2*EPC]
+    float* chs = stage + 256 * 2 * EPC;        // [C] channel sums
+    float* chq = chs + C;                      // [C] channel sums of squares
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, f = blockIdx.y;
+    const int CPR = C / EPC;
+    const int TC = CPR < 256 ? CPR : 256;
+    const int TR = 256 / TC;
+    const int tc = tid % TC, tr = tid / TC;
+    const bool active = tr < TR;
+    const int row0 = chunk * R;
+    const int rows = min(R, HW - row0);
+    const T* base = x + ((long)f * HW + row0) * ldx;
+    for (int cc0 = 0; cc0 < CPR; cc0 += TC) {
+        const int cc = cc0 + tc;
+        float s[EPC], q[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+        if (active && cc < CPR) {
+            for (int r = tr; r < rows; r += TR) {
+                const u32x4 v = *(const u32x4*)(base + (long)r * ldx + cc * EPC);
+                float e[EPC];
+                chunk_to_f32<T>(v, e);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) { s[j] += e[j]; q[j] += e[j] * e[j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) { stage[tid * 2 * EPC + j] = s[j]; stage[tid * 2 * EPC + EPC + j] = q[j]; }
+        __syncthreads();
+        if (tr == 0 && cc < CPR) {
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                float ss = 0.f, qq = 0.f;
+                for (int t2 = 0; t2 < TR; ++t2) {
+                    ss += stage[(t2 * TC + tc) * 2 * EPC + j];
+                    qq += stage[(t2 * TC + tc) * 2 * EPC + EPC + j];
+                }
+                chs[cc * EPC + j] = ss;
+                chq[cc * EPC + j] = qq;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < G) {
+        const int cpg = C / G;
+        float ss = 0.f, qq = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { ss += chs[c]; qq += chq[c]; }
+        const float n = (float)rows * (float)cpg;
+        const float mean = ss / n;
+        float m2 = qq - ss * mean;
+        if (m2 < 0.f) m2 = 0.f;
+        float* o = part + (((long)f * nchunk + chunk) * G + tid) * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+}
+
+// ---- GroupNorm pass 2: merge partials -> (mean, rstd) per (stat, group) --------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int fps, int G,
+                                                          float eps, float* __restrict__ stats) {
+    // 256 threads: 8 lanes per group merge strided subsets, then lane 0 merges the 8 results in order.
+    __shared__ double sh[256][3];
+    const int tid = threadIdx.x;
+    const int grp = tid >> 3, sub = tid & 7;
+    const int stat = blockIdx.x;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    if (grp < G) {
+        const int total = fps * nchunk;
+        for (int i = sub; i < total; i += 8) {
+            const float* pp = part + (((long)stat * fps * nchunk + i) * G + grp) * 3;
+            const double nb = pp[0], mb = pp[1], qb = pp[2];
+            const double nn = n + nb;
+            const double d = mb - mean;
+            mean += d * nb / nn;
+            m2 += qb + d * d * n * nb / nn;
+            n = nn;
+        }
+    }
+    sh[tid][0] = n; sh[tid][1] = mean; sh[tid][2] = m2;
+    __syncthreads();
+    if (grp < G && sub == 0) {
+        for (int k = 1; k < 8; ++k) {
+            const double nb = sh[tid + k][0], mb = sh[tid + k][1], qb = sh[tid + k][2];
+            if (nb == 0.0) continue;
+            const double nn = n + nb;
+            const double d = mb - mean;
+            mean += d * nb / nn;
+            m2 += qb + d * d * n * nb / nn;
+            n = nn;
+        }
+        const double var = m2 / n;
+        stats[((long)stat * G + grp) * 2 + 0] = (float)mean;
+        stats[((long)stat * G + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---- GroupNorm pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU -----------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                       int HW, int C, int G, int fps, int R,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int act) {
+    constexpr int EPC = Elem<T>::EPC;
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, f = blockIdx.y;
+    const int CPR = C / EPC;
+    const int TC = CPR < 256 ? CPR : 256;
+    const int TR = 256 / TC;
+    const int tc = tid % TC, tr = tid / TC;
+    if (tr >= TR) return;
+    const int row0 = chunk * R;
+    const int rows = min(R, HW - row0);
+    const int cpg = C / G;
+    const float* st = stats + (long)(f / fps) * G * 2;
+    const T* xb = x + ((long)f * HW + row0) * ldx;
+    T* yb = y + ((long)f * HW + row0) * ldy;
+    for (int cc = tc; cc < CPR; cc += TC) {
+        float sc[EPC], sh[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            const int c = cc * EPC + j;
+            const int gi = c / cpg;
+            const float mean = st[gi * 2], rstd = st[gi * 2 + 1];
+            sc[j] = rstd * gamma[c];
+            sh[j] = beta[c] - mean * sc[j];
+        }
+        for (int r = tr; r < rows; r += TR) {
+            const u32x4 v = *(const u32x4*)(xb + (long)r * ldx + cc * EPC);
+            float e[EPC];
+            chunk_to_f32<T>(v, e);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                float o = e[j] * sc[j] + sh[j];
+                if (act == 1) o = silu_f(o);
+                e[j] = o;
+            }
+            *(u32x4*)(yb + (long)r * ldy + cc * EPC) = f32_to_chunk<T>(e);
+        }
+    }
+}
+
+// ---- LayerNorm: one wave per row, row held in registers ------------------------------------
+template <typename T, int MAXC>  // MAXC = chunks per lane
+__global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int M, int C,
+                                                 float eps, const float* __restrict__ gamma, const float* __restrict__ beta) {
+    constexpr int EPC = Elem<T>::EPC;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int CPR = C / EPC;
+    float e[MAXC][EPC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < CPR) {
+            const u32x4 v = *(const u32x4*)(x + row * ldx + cc * EPC);
+            chunk_to_f32<T>(v, e[i]);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) s += e[i][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) e[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < CPR) {
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) { const float d = e[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < CPR) {
+            float o[EPC];
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                const int c = cc * EPC + j;
+                o[j] = (e[i][j] - mean) * rstd * gamma[c] + beta[c];
+            }
+            *(u32x4*)(y + row * ldy + cc * EPC) = f32_to_chunk<T>(o);
+        }
+    }
+}
+
+// ---- row softmax: y = softmax(scale * x), x fp32, one workgroup per row --------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                           int cols, float scale) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const float* xr = x + (long)blockIdx.x * ldx;
+    T* yr = y + (long)blockIdx.x * ldy;
+    float m = -INFINITY;
+    for (int c = tid; c < cols; c += 256) m = fmaxf(m, xr[c] * scale);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < cols; c += 256) s += __expf(xr[c] * scale - m);
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / s;
+    for (int c = tid; c < cols; c += 256) Elem<T>::st(yr + c, __expf(xr[c] * scale - m) * inv);
+}
+
+template <typename T>
+int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
+    constexpr int EPC = Elem<T>::EPC;
+    const int R = gn_rows_per_chunk(p.HW);
+    const int nchunk = (p.HW + R - 1) / R;
+    float* part = (float*)p.workspace;
+    float* stats = part + (size_t)p.F * nchunk * p.groups * 3;
+    const size_t smem = (size_t)256 * 2 * EPC * 4 + (size_t)2 * p.C * 4;
+    hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
+                       R, nchunk, part);
+    GEO4D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.F / p.frames_per_stat), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
+                       p.groups, p.eps, stats);
+    GEO4D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
+                       p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act);
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
+template <typename T>
+int layernorm_typed(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* g, const float* b,
+                    hipStream_t s) {
+    constexpr int EPC = Elem<T>::EPC;
+    const int per_lane = (C / EPC + 63) / 64;
+    const dim3 grid((M + 3) / 4);
+#define LN_LAUNCH(MC) hipLaunchKernelGGL((ln_kernel<T, MC>), grid, dim3(256), 0, s, (const T*)x, ldx, (T*)y, ldy, M, C, eps, g, b)
+    if (per_lane <= 1) LN_LAUNCH(1);
+    else if (per_lane <= 2) LN_LAUNCH(2);
+    else if (per_lane <= 3) LN_LAUNCH(3);
+    else if (per_lane <= 5) LN_LAUNCH(5);
+    else if (per_lane <= 10) LN_LAUNCH(10);
+    else { geo4d_set_error("layernorm: C too large"); return GEO4D_ENOTSUP; }
+#undef LN_LAUNCH
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
+}  // namespace
+
+extern "C" size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat) {
+    const int R = gn_rows_per_chunk(HW);
+    const int nchunk = (HW + R - 1) / R;
+    return ((size_t)F * nchunk * groups * 3 + (size_t)(F / frames_per_stat) * groups * 2) * sizeof(float);
+}
+
+extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
+    if (!pp) return GEO4D_EINVAL;
+    const geo4d_groupnorm_t& p = *pp;
+    const int esz = p.dtype == GEO4D_F32 ? 4 : 2, epc = 16 / esz;
+    if (p.dtype < 0 || p.dtype > 2) { geo4d_set_error("groupnorm: bad dtype"); return GEO4D_EINVAL; }
+    if (p.F <= 0 || p.HW <= 0 || p.C <= 0 || p.groups <= 0 || p.groups > 32 || p.C % p.groups || p.C % epc) {
+        geo4d_set_error("groupnorm: need C % groups == 0, C % (16 B) == 0, groups <= 32");
+        return GEO4D_EINVAL;
+    }
+    if (p.frames_per_stat <= 0 || p.F % p.frames_per_stat) { geo4d_set_error("groupnorm: F % frames_per_stat"); return GEO4D_EINVAL; }
+    if ((p.ldx * esz) % 16 || (p.ldy * esz) % 16 || ((uintptr_t)p.x % 16) || ((uintptr_t)p.y % 16)) { geo4d_set_error("groupnorm: alignment"); return GEO4D_EINVAL; }
+    if (p.workspace_bytes < geo4d_groupnorm_workspace(p.F, p.HW, p.groups, p.frames_per_stat)) { geo4d_set_error("groupnorm: workspace too small"); return GEO4D_EINVAL; }
+    if (p.F > 65535) { geo4d_set_error("groupnorm: too many frames"); return GEO4D_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    switch (p.dtype) {
+        case GEO4D_F32: return groupnorm_typed<float>(p, s);
+        case GEO4D_BF16: return groupnorm_typed<bf16_t>(p, s);
+        default: return groupnorm_typed<f16_t>(p, s);
+    }
+}
+
+extern "C" int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
+                               const float* beta, int dtype, void* stream) {
+    const int esz = dtype == GEO4D_F32 ? 4 : 2, epc = 16 / esz;
+    if (dtype < 0 || dtype > 2 || M <= 0 || C <= 0 || C % epc || (ldx * esz) % 16 || (ldy * esz) % 16 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) {
+        geo4d_set_error("layernorm: bad arguments");
+        return GEO4D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case GEO4D_F32: return layernorm_typed<float>(x, ldx, y, ldy, M, C, eps, gamma, beta, s);
+        case GEO4D_BF16: return layernorm_typed<bf16_t>(x, ldx, y, ldy, M, C, eps, gamma, beta, s);
+        default: return layernorm_typed<f16_t>(x, ldx, y, ldy, M, C, eps, gamma, beta, s);
+    }
+}
+
+extern "C" int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
+                                  void* stream) {
+    if (rows <= 0 || cols <= 0 || out_dtype < 0 || out_dtype > 2 || rows > 2147483647L) { geo4d_set_error("softmax_rows: bad arguments"); return GEO4D_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)rows);
+    switch (out_dtype) {
+        case GEO4D_F32: hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, s, x, ldx, (float*)y, ldy, cols, scale); break;
+        case GEO4D_BF16: hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, (bf16_t*)y, ldy, cols, scale); break;
+        default: hipLaunchKernelGGL(softmax_rows_kernel<f16_t>, grid, dim3(256), 0, s, x, ldx, (f16_t*)y, ldy, cols, scale); break;
+    }
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}

@@ -1,0 +1,273 @@
+"""Torch-tensor front-ends of the C ABI (include/geo4d_hip.h).
+
+PyTorch is plumbing only: it owns device memory (``torch.empty``) and the HIP stream. Every function takes 2-D
+"token" views ``[rows, channels]`` (unit inner stride, arbitrary row pitch), hands raw device pointers to
+libgeo4d_hip.so and returns immediately (stream ordered, hipGraph-capturable). There is no CPU/eager fallback:
+tensors that are not on a HIP device raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, Attention, ConvGemm, GroupNorm
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_TD = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+
+
+def dt_code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"geo4d_amd: unsupported dtype {dtype} (float32, bfloat16, float16 only)")
+
+
+def k_align(dtype):
+    """K / Cin granularity of conv_gemm in elements: one 128-byte LDS slab."""
+    return 32 if dtype == torch.float32 else 64
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, what):
+    if not t.is_cuda:
+        raise _lib.Geo4DNativeError(f"geo4d_amd.ops: `{what}` lives on {t.device}; the HIP path needs a GPU tensor "
+                                    "(there is no CPU fallback)")
+    return t
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _ld(t):
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), f"need a [rows, cols] view with unit inner stride, got {t.shape} {t.stride()}"
+    return t.stride(0)
+
+
+def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout=1, Wout=1, KT=1, KH=1, KW=1,
+              pt=0, ph=0, pw=0, stride=1, ups=1, bias=None, bias_per_row=False, rowbias=None, rowbias_div=0,
+              residual=None, ldr=0, act=0, out_nchw=False, alpha=1.0, batch=1, a_bs=0, w_bs=0, o_bs=0, r_bs=0,
+              tile_hint=0):
+    lib = _lib.load()
+    _dev(a, "A"); _dev(w, "W"); _dev(out, "out")
+    assert a.dtype == w.dtype, (a.dtype, w.dtype)
+    p = ConvGemm()
+    p.A, p.W, p.O = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.bias, p.rowbias, p.R = _ptr(bias), _ptr(rowbias), _ptr(residual)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.is_contiguous()
+    if residual is not None:
+        assert residual.dtype == out.dtype
+    p.lda, p.ldw, p.ldo, p.ldr = lda, ldw, ldo, ldr
+    p.a_bs, p.w_bs, p.o_bs, p.r_bs = a_bs, w_bs, o_bs, r_bs
+    p.M, p.N, p.K, p.batch, p.Cin = M, N, K, batch, Cin
+    p.T, p.Hin, p.Win, p.Hout, p.Wout = T, Hin, Win, Hout, Wout
+    p.KT, p.KH, p.KW, p.pt, p.ph, p.pw, p.stride, p.ups = KT, KH, KW, pt, ph, pw, stride, ups
+    p.rowbias_div, p.bias_per_row, p.act = rowbias_div, int(bias_per_row), act
+    p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = dt_code(a.dtype), dt_code(out.dtype), int(out_nchw), tile_hint
+    p.alpha = alpha
+    _lib.check(lib.geo4d_conv_gemm(C.byref(p), _stream()), "geo4d_conv_gemm")
+    return out
+
+
+def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0):
+    """x [M, K] (row pitch free), w packed [N, K]; GEGLU (act=2) returns [M, N/2]."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (w.shape, x.shape)
+    if out is None:
+        out = torch.empty((M, N // 2 if act == 2 else N), device=x.device, dtype=out_dtype or x.dtype)
+    return conv_gemm(x, w, out, M=M, N=N, K=K, Cin=K, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), bias=bias,
+                     residual=residual, ldr=_ld(residual) if residual is not None else 0, act=act, alpha=alpha,
+                     tile_hint=tile_hint)
+
+
+def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, ups=1, T=1, rowbias=None, rowbias_div=0,
+           residual=None, act=0, out=None, out_dtype=None, out_nchw=False, tile_hint=0):
+    """x tokens [F*Hin*Win, Cin]; w packed [N, KH*KW*Cin]. Output tokens [F*Hout*Wout, N] (or NCTHW fp32/..)."""
+    Cin = x.shape[1]
+    N = w.shape[0]
+    Hs, Ws = Hin * ups, Win * ups
+    Hout = (Hs + 2 * pad - KH) // stride + 1
+    Wout = (Ws + 2 * pad - KW) // stride + 1
+    M = F * Hout * Wout
+    assert x.shape[0] == F * Hin * Win, (x.shape, F, Hin, Win)
+    assert w.shape[1] == KH * KW * Cin, (w.shape, KH, KW, Cin)
+    if out is None:
+        if out_nchw:
+            out = torch.empty((F // T, N, T, Hout, Wout), device=x.device, dtype=out_dtype or torch.float32)
+        else:
+            out = torch.empty((M, N), device=x.device, dtype=out_dtype or x.dtype)
+    conv_gemm(x, w, out, M=M, N=N, K=KH * KW * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=N if out_nchw else _ld(out), T=T,
+              Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=KH, KW=KW, ph=pad, pw=pad, stride=stride, ups=ups, bias=bias,
+              rowbias=rowbias, rowbias_div=rowbias_div, residual=residual,
+              ldr=_ld(residual) if residual is not None else 0, act=act, out_nchw=out_nchw, tile_hint=tile_hint)
+    return out, Hout, Wout
+
+
+def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None):
+    """nn.Conv3d kernel (3,1,1), padding (1,0,0) on tokens [(b t) hw, C]; w packed [N, 3*C]."""
+    Cin = x.shape[1]
+    N = w.shape[0]
+    M = B * T * HW
+    assert x.shape[0] == M and w.shape[1] == 3 * Cin
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=x.dtype)
+    return conv_gemm(x, w, out, M=M, N=N, K=3 * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), T=T, Hin=HW, Win=1,
+                     Hout=HW, Wout=1, KT=3, pt=1, bias=bias, residual=residual,
+                     ldr=_ld(residual) if residual is not None else 0)
+
+
+def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias_per_row=False, alpha=1.0):
+    """out[z] = alpha * a[z] @ b[z]^T (+bias); a [.., K] rows, b [.., K] rows (both K-major)."""
+    return conv_gemm(a, b, out, M=M, N=N, K=K, Cin=K, lda=_ld(a), ldw=_ld(b), ldo=_ld(out), batch=batch, a_bs=a_bs,
+                     w_bs=b_bs, o_bs=o_bs, bias=bias, bias_per_row=bias_per_row, alpha=alpha)
+
+
+_gn_ws = {}
+
+
+def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=False, out=None):
+    lib = _lib.load()
+    _dev(x, "x")
+    Cc = x.shape[1]
+    assert x.shape[0] == F * HW, (x.shape, F, HW)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    if out is None:
+        out = torch.empty((F * HW, Cc), device=x.device, dtype=x.dtype)
+    need = lib.geo4d_groupnorm_workspace(F, HW, groups, frames_per_stat)
+    ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+    p = GroupNorm()
+    p.x, p.y, p.gamma, p.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    p.workspace, p.workspace_bytes = ws.data_ptr(), need
+    p.ldx, p.ldy = _ld(x), _ld(out)
+    p.F, p.HW, p.C, p.groups, p.frames_per_stat = F, HW, Cc, groups, frames_per_stat
+    p.act, p.dtype, p.eps = int(silu), dt_code(x.dtype), eps
+    _lib.check(lib.geo4d_groupnorm(C.byref(p), _stream()), "geo4d_groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    lib = _lib.load()
+    _dev(x, "x")
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty((M, Cc), device=x.device, dtype=x.dtype)
+    _lib.check(lib.geo4d_layernorm(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), M, Cc, eps, gamma.data_ptr(),
+                                   beta.data_ptr(), dt_code(x.dtype), _stream()), "geo4d_layernorm")
+    return out
+
+
+def softmax_rows(x, scale, out_dtype):
+    lib = _lib.load()
+    _dev(x, "x")
+    assert x.dtype == torch.float32
+    rows, cols = x.shape
+    out = torch.empty((rows, cols), device=x.device, dtype=out_dtype)
+    _lib.check(lib.geo4d_softmax_rows(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), rows, cols, scale,
+                                      dt_code(out_dtype), _stream()), "geo4d_softmax_rows")
+    return out
+
+
+def attention(q, kv, *, B, H, Nq, scale, out=None):
+    """q [B*Nq, >=H*64] view; kv = list of (k, v, Nk, kv_div) with k/v [(B/kv_div)*Nk, >=H*64] views."""
+    lib = _lib.load()
+    _dev(q, "q")
+    if out is None:
+        out = torch.empty((B * Nq, H * 64), device=q.device, dtype=q.dtype)
+    p = Attention()
+    p.q, p.o, p.ldq, p.ldo = q.data_ptr(), out.data_ptr(), _ld(q), _ld(out)
+    assert 1 <= len(kv) <= 2
+    for i, (k, v, nk, div) in enumerate(kv):
+        assert k.dtype == q.dtype and v.dtype == q.dtype
+        p.k[i], p.v[i], p.ldk[i], p.ldv[i], p.Nk[i], p.kv_div[i] = k.data_ptr(), v.data_ptr(), _ld(k), _ld(v), nk, div
+    p.B, p.H, p.Nq, p.nseg, p.head_dim, p.dtype, p.scale = B, H, Nq, len(kv), 64, dt_code(q.dtype), scale
+    _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
+    return out
+
+
+def temporal_attention(q, k, v, *, B, T, HW, H, scale, out=None):
+    lib = _lib.load()
+    _dev(q, "q")
+    if out is None:
+        out = torch.empty((B * T * HW, H * 64), device=q.device, dtype=q.dtype)
+    _lib.check(lib.geo4d_temporal_attention(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(),
+                                            _ld(out), B, T, HW, H, 64, scale, dt_code(q.dtype), _stream()),
+               "geo4d_temporal_attention")
+    return out
+
+
+def tokens_from_ncthw(src0, src1, cpad, dtype):
+    """[B,C0,T,H,W] (+[B,C1,T,H,W]) fp32 -> tokens [(b t) h w, cpad] of `dtype`, zero padded channels."""
+    lib = _lib.load()
+    _dev(src0, "src0")
+    assert src0.dtype == torch.float32 and src0.is_contiguous()
+    B, C0, T, H, W = src0.shape
+    C1 = 0
+    if src1 is not None:
+        assert src1.dtype == torch.float32 and src1.is_contiguous() and src1.shape[0] == B and src1.shape[2:] == src0.shape[2:]
+        C1 = src1.shape[1]
+    out = torch.empty((B * T * H * W, cpad), device=src0.device, dtype=dtype)
+    _lib.check(lib.geo4d_tokens_from_ncthw(src0.data_ptr(), C0, _ptr(src1), C1, out.data_ptr(), cpad, B, T, H * W,
+                                           dt_code(dtype), _stream()), "geo4d_tokens_from_ncthw")
+    return out
+
+
+def concat_channels(a, b):
+    lib = _lib.load()
+    _dev(a, "a")
+    M, Ca = a.shape
+    Cb = b.shape[1]
+    assert b.shape[0] == M and a.dtype == b.dtype
+    out = torch.empty((M, Ca + Cb), device=a.device, dtype=a.dtype)
+    _lib.check(lib.geo4d_concat_channels(a.data_ptr(), _ld(a), Ca, b.data_ptr(), _ld(b), Cb, out.data_ptr(), _ld(out), M,
+                                         dt_code(a.dtype), _stream()), "geo4d_concat_channels")
+    return out
+
+
+def timestep_embedding(t, freqs):
+    """t int64 [B] on device, freqs fp32 [dim/2] -> fp32 [B, dim] = [cos | sin]."""
+    lib = _lib.load()
+    _dev(t, "t")
+    assert t.dtype == torch.int64 and freqs.dtype == torch.float32
+    B, half = t.shape[0], freqs.shape[0]
+    out = torch.empty((B, 2 * half), device=t.device, dtype=torch.float32)
+    _lib.check(lib.geo4d_timestep_embedding(t.data_ptr(), freqs.data_ptr(), out.data_ptr(), B, 2 * half, _stream()),
+               "geo4d_timestep_embedding")
+    return out
+
+
+def linear_small(x, w, bias=None, *, add=None, act_in=False, act_out=False, out=None):
+    """fp32 [M,K] x fp32 [N,K]^T for M = batch-sized rows (time / fps / ResBlock embedding MLPs)."""
+    lib = _lib.load()
+    _dev(x, "x")
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    _lib.check(lib.geo4d_linear_small(x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _ptr(bias), _ptr(add),
+                                      _ld(add) if add is not None else 0, out.data_ptr(), _ld(out), M, N, K, int(act_in),
+                                      int(act_out), _stream()), "geo4d_linear_small")
+    return out
+
+
+def ddim_step(x, v, coef, step_index, noise=None, pred_x0=None):
+    lib = _lib.load()
+    _dev(x, "x")
+    assert x.dtype == torch.float32 and v.dtype == torch.float32 and x.is_contiguous() and v.is_contiguous()
+    assert coef.dtype == torch.float32 and step_index.dtype == torch.int32
+    _lib.check(lib.geo4d_ddim_step(x.data_ptr(), v.data_ptr(), _ptr(noise), _ptr(pred_x0), coef.data_ptr(),
+                                   step_index.data_ptr(), x.numel(), _stream()), "geo4d_ddim_step")
+    return x
+
+
+def advance_index(idx, delta):
+    lib = _lib.load()
+    _lib.check(lib.geo4d_advance_index(idx.data_ptr(), delta, _stream()), "geo4d_advance_index")

@@ -1,0 +1,54 @@
+"""One-time weight re-layout from the reference ``state_dict`` format into the kernel format.
+
+Runs once per model load (not on the hot path): conv weights become ``[Cout][taps][Cin_pad]`` K-major rows,
+GEGLU projections get their value/gate rows interleaved in blocks of 32 so the GEMM epilogue can multiply them.
+"""
+import torch
+
+from .ops import k_align
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def pack_linear(w, dtype):
+    """nn.Linear / 1x1 conv weight [N, K(,1,1)] -> [N, Kpad]."""
+    w = w.reshape(w.shape[0], -1)
+    kp = pad_to(w.shape[1], k_align(dtype))
+    if kp != w.shape[1]:
+        w = torch.nn.functional.pad(w, (0, kp - w.shape[1]))
+    return w.to(dtype).contiguous()
+
+
+def pack_conv2d(w, dtype, cin_pad=None):
+    """nn.Conv2d weight [Cout, Cin, KH, KW] -> [Cout, KH*KW*Cin_pad] (tap-major, channel fastest)."""
+    co, ci, kh, kw = w.shape
+    cp = cin_pad or pad_to(ci, k_align(dtype))
+    w = w.permute(0, 2, 3, 1)
+    if cp != ci:
+        w = torch.nn.functional.pad(w, (0, cp - ci))
+    return w.reshape(co, kh * kw * cp).to(dtype).contiguous()
+
+
+def pack_conv3d_t(w, dtype):
+    """nn.Conv3d weight [Cout, Cin, 3, 1, 1] -> [Cout, 3*Cin]."""
+    co, ci, kt, kh, kw = w.shape
+    assert kh == 1 and kw == 1
+    return w.reshape(co, ci, kt).permute(0, 2, 1).reshape(co, kt * ci).to(dtype).contiguous()
+
+
+def geglu_perm(inner, device=None):
+    """Row order that interleaves 32 value rows with their 32 gate rows (GEGLU.proj: [value | gate])."""
+    assert inner % 32 == 0
+    j = torch.arange(inner // 32, device=device)
+    blk = torch.arange(32, device=device)
+    val = (j[:, None] * 32 + blk[None, :])
+    gate = val + inner
+    return torch.cat([val, gate], dim=1).reshape(-1)
+
+
+def pack_geglu(w, b, dtype):
+    inner = w.shape[0] // 2
+    perm = geglu_perm(inner, w.device)
+    return pack_linear(w[perm], dtype), b[perm].float().contiguous()

@@ -1,0 +1,129 @@
+/* geo4d_hip.h — C ABI of libgeo4d_hip.so, the MI355X (gfx950 / CDNA4) kernel library behind the Geo4D
+ * denoise + decode hot path.
+ *
+ * The reference (jzr99/Geo4D) has NO native boundary: its plug-in surface is the Python config registry
+ * (utils/utils.py:27-42 instantiate_from_config) and below it only PyTorch ATen ops + xformers. This header is
+ * therefore the boundary a reference maintainer would bind with ctypes: every entry point
+ * replaces the ATen/xformers call(s) cited next to it. Conventions:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller (PyTorch allocator);
+ *     the library never allocates, frees, synchronises or copies — every call only enqueues kernels on `stream`
+ *     (a hipStream_t passed as void*), so every call is hipGraph-capturable;
+ *   - activations are channels-last "tokens": row (b*T + t)*H*W + y*W + x, `ld*` = row pitch in ELEMENTS;
+ *     dtype codes: 0 = f32 (exact parity mode, v_mfma_f32_32x32x2_f32), 1 = bf16, 2 = f16 (MFMA 32x32x16, fp32 acc);
+ *   - every row pitch / base pointer must be 16-byte aligned (kernels move 16-byte chunks);
+ *   - return 0 on success, negative errno-style code otherwise (-22 EINVAL, -95 ENOTSUP, -5 EIO = HIP launch
+ *     error); geo4d_last_error() returns a thread-local message. Kernels never abort().
+ *   - thread model: one host thread per device/stream; no global mutable state except per-kernel attribute caches.
+ */
+#ifndef GEO4D_HIP_H
+#define GEO4D_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEO4D_ABI_VERSION 1
+
+/* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
+ * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
+ * ae_modules.py:199-226), F.interpolate(nearest,2x)+conv (openaimodel3d.py:99-105; ae_modules.py:123-127),
+ * F.conv3d (3,1,1) (openaimodel3d.py:257-266), torch.bmm (ae_modules.py:64,72), `+ emb_out[..., None, None]`
+ * (openaimodel3d.py:222-230), residual adds, GEGLU (attention.py:415-422), SiLU. */
+typedef struct geo4d_conv_gemm_t {
+    const void* A;       /* input tokens [F*Hin*Win][lda]                              */
+    const void* W;       /* packed weights [N][ldw], K = KT*KH*KW*Cin, tap-major        */
+    void* O;             /* output [M][ldo] (or NCTHW when out_nchw)                    */
+    const float* bias;   /* [N] (or [M] when bias_per_row), may be NULL                 */
+    const float* rowbias;/* [M/rowbias_div][N] fp32 added per row group, may be NULL    */
+    const void* R;       /* residual [M][ldr], dtype = out_dtype, may be NULL           */
+    long lda, ldw, ldo, ldr;
+    long a_bs, w_bs, o_bs, r_bs; /* batch strides in elements (batched GEMM)            */
+    int M, N, K, batch;
+    int Cin;             /* channels per tap; multiple of 128 B worth of elements       */
+    int T, Hin, Win, Hout, Wout;
+    int KT, KH, KW, pt, ph, pw, stride, ups;
+    int rowbias_div;
+    int bias_per_row;
+    int act;             /* 0 none, 1 SiLU, 2 GEGLU (packed pairs of 32 columns)        */
+    int dtype;           /* A/W element type                                            */
+    int out_dtype;       /* O/R element type                                            */
+    int out_nchw;        /* 1: store O as [B][N][T][Hout*Wout]                          */
+    int tile_hint;       /* 0 auto, 1..5 force a tile configuration (tests)             */
+    float alpha;
+} geo4d_conv_gemm_t;
+int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);
+
+/* GroupNorm(groups) [+SiLU] over tokens [F][HW][C]; statistics per (F / frames_per_stat, group) in fp32.
+ * replaces nn.GroupNorm / GroupNormSpecific + nn.SiLU (basics.py:76-87; openaimodel3d.py:151-153,174-176,256-266;
+ * attention.py:265,331; ae_modules.py:10-16). */
+typedef struct geo4d_groupnorm_t {
+    const void* x; void* y;
+    const float* gamma; const float* beta;
+    void* workspace; size_t workspace_bytes;
+    long ldx, ldy;
+    int F, HW, C, groups, frames_per_stat;
+    int act;             /* 0 none, 1 SiLU / swish                                       */
+    int dtype;
+    float eps;
+} geo4d_groupnorm_t;
+size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat);
+int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);
+
+/* LayerNorm over the last dim; replaces nn.LayerNorm (attention.py:225-227). */
+int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
+                    const float* beta, int dtype, void* stream);
+
+/* y = softmax(scale * x) per row, x fp32; replaces F.softmax in the VAE AttnBlock (ae_modules.py:66-68). */
+int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
+                       void* stream);
+
+/* Fused multi-head attention, d_head = 64, no mask, up to two key/value sets with independent softmaxes whose
+ * outputs are summed. q rows: b*Nq + i, head h at columns [64h, 64h+64). K/V rows of set s: (b / kv_div[s])*Nk[s] + j.
+ * replaces CrossAttention.forward / efficient_forward = xformers.ops.memory_efficient_attention
+ * (attention.py:81-144, 146-209). */
+typedef struct geo4d_attention_t {
+    const void* q; void* o;
+    const void* k[2]; const void* v[2];
+    long ldq, ldo, ldk[2], ldv[2];
+    int Nk[2], kv_div[2];
+    int B, H, Nq, nseg, head_dim, dtype;
+    float scale;
+} geo4d_attention_t;
+int geo4d_attention(const geo4d_attention_t* p, void* stream);
+
+/* Self-attention over T <= 16 frames for every (batch, pixel, head); tokens stay frame-major [B*T][HW][C].
+ * replaces the einsum/softmax path of CrossAttention inside TemporalTransformer (attention.py:101-125, 365-412). */
+int geo4d_temporal_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                             int B, int T, int HW, int H, int head_dim, float scale, int dtype, void* stream);
+
+/* [B,C0,T,H,W] (+ [B,C1,T,H,W]) fp32 -> tokens [(b t) hw][Cpad] (zero padded);
+ * replaces torch.cat([x] + c_concat, 1) + rearrange (ddpm3d.py:2540-2544; openaimodel3d.py:588). */
+int geo4d_tokens_from_ncthw(const float* src0, int C0, const float* src1, int C1, void* out, int Cpad, int B, int T, int HW,
+                            int dtype, void* stream);
+
+/* out[m] = [a[m] | b[m]]; replaces torch.cat([h, hs.pop()], dim=1) (openaimodel3d.py:624-626). */
+int geo4d_concat_channels(const void* a, long lda, int Ca, const void* b, long ldb, int Cb, void* out, long ldo, long M,
+                          int dtype, void* stream);
+
+/* out[b] = [cos(t_b * f) | sin(t_b * f)]; replaces timestep_embedding (utils_diffusion.py:8-28). */
+int geo4d_timestep_embedding(const long* t, const float* freqs, float* out, int B, int dim, void* stream);
+
+/* out = act_out(act_in(x) . W^T + bias) + add, all fp32, M small; replaces time_embed / fps_embedding /
+ * ResBlock.emb_layers (openaimodel3d.py:367-384, 166-172, 222). */
+int geo4d_linear_small(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* add, long ldadd,
+                       float* out, long ldo, int M, int N, int K, int act_in, int act_out, void* stream);
+
+/* In-place DDIM update of x with v-prediction and dynamic rescale; coefficients are read from
+ * coef[*step_index] (6 floats per step) so one captured hipGraph replays for every step.
+ * replaces DDIMSampler.p_sample_ddim arithmetic (ddim.py:232-277) + DDPM.predict_* (ddpm3d.py:278-290). */
+int geo4d_ddim_step(float* x, const float* v, const float* noise, float* pred_x0, const float* coef, const int* step_index,
+                    long n, void* stream);
+int geo4d_advance_index(int* idx, int delta, void* stream);
+
+const char* geo4d_last_error(void);
+int geo4d_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

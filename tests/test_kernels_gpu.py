@@ -1,0 +1,284 @@
+"""Kernel-level parity of the HIP path (through the C ABI) against plain PyTorch fp32 math on the same inputs.
+
+Tolerances (relative L2, printed for every case): f32 mode 2e-5 (exact-f32 MFMA, only summation order differs);
+bf16 / f16 modes compare against the fp32 result computed from the SAME rounded inputs, so what remains is the
+output rounding + fp32 accumulation order: 6e-3 (bf16), 1e-3 (f16).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 6e-3, torch.float16: 1e-3}
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def check(name, got, ref, dtype, scale=1.0):
+    e = rel(got.float(), ref.float())
+    m = (got.float() - ref.float()).abs().max().item()
+    print(f"[{name}] dtype={dtype} rel_l2={e:.3e} max_abs={m:.3e} tol={TOL[dtype] * scale:.1e}")
+    assert math.isfinite(e) and e <= TOL[dtype] * scale, f"{name}: rel_l2 {e:.3e} > {TOL[dtype] * scale:.1e}"
+
+
+def rnd(shape, dev, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_linear_bias_residual(dev, dtype, tile):
+    from geo4d_amd import ops
+    M, K, N = 300, 320, 200  # ragged M and N
+    x, w = rnd((M, K), dev, dtype, 1), rnd((N, K), dev, dtype, 2, 0.05)
+    b = rnd((N,), dev, torch.float32, 3)
+    r = rnd((M, N), dev, dtype, 4)
+    out = ops.linear(x, w, b, residual=r, tile_hint=tile)
+    ref = x.float() @ w.float().t() + b + r.float()
+    check(f"linear tile{tile}", out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_is_not_transposed(dev, dtype):
+    """A = I with an asymmetric W catches a swapped C/D mapping (cdna_hip_programming.md rule 16)."""
+    from geo4d_amd import ops
+    K = 128
+    x = torch.eye(K, device=dev, dtype=dtype)
+    w = (torch.arange(96 * K, device=dev, dtype=torch.float32).reshape(96, K) % 17 - 8).to(dtype)
+    out = ops.linear(x, w)
+    check("identity", out, w.float().t(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_silu_and_strided_views(dev, dtype):
+    from geo4d_amd import ops
+    M, K, N = 257, 128, 64
+    big = rnd((M, 3 * K), dev, dtype, 5)
+    x = big[:, K:2 * K]  # column slice: row pitch 3K
+    w = rnd((N, K), dev, dtype, 6, 0.1)
+    outbuf = torch.zeros((M, 2 * N), device=dev, dtype=dtype)
+    ops.linear(x, w, None, act=1, out=outbuf[:, N:])
+    ref = TF.silu(x.float() @ w.float().t())
+    check("linear silu strided", outbuf[:, N:], ref, dtype)
+    assert outbuf[:, :N].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu(dev, dtype):
+    from geo4d_amd import ops, pack
+    M, K, inner = 200, 64 if dtype != torch.float32 else 32, 128
+    x = rnd((M, K), dev, dtype, 7)
+    w, b = rnd((2 * inner, K), dev, torch.float32, 8, 0.2), rnd((2 * inner,), dev, torch.float32, 9)
+    wp, bp = pack.pack_geglu(w, b, dtype)
+    out = ops.linear(x, wp, bp, act=2)
+    h = x.float() @ w.to(dtype).float().t() + b
+    ref = h[:, :inner] * TF.gelu(h[:, inner:])
+    assert out.shape == (M, inner)
+    check("geglu", out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [dict(stride=1, ups=1), dict(stride=2, ups=1), dict(stride=1, ups=2)])
+def test_conv3x3(dev, dtype, cfg):
+    from geo4d_amd import ops, pack
+    F, H, W, Ci, Co = 3, 9, 7, 64, 96
+    x_nchw = rnd((F, Ci, H, W), dev, dtype, 10)
+    w = rnd((Co, Ci, 3, 3), dev, torch.float32, 11, 0.05)
+    b = rnd((Co,), dev, torch.float32, 12)
+    emb = rnd((F, Co), dev, torch.float32, 13)
+    x = x_nchw.permute(0, 2, 3, 1).reshape(F * H * W, Ci).contiguous()
+    wp = pack.pack_conv2d(w, dtype)
+    xin = x_nchw.float()
+    if cfg["ups"] == 2:
+        xin = TF.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = TF.conv2d(xin, w.to(dtype).float(), b, stride=cfg["stride"], padding=1) + emb[:, :, None, None]
+    Ho, Wo = ref.shape[-2:]
+    out, ho, wo = ops.conv2d(x, wp, b, F=F, Hin=H, Win=W, KH=3, KW=3, stride=cfg["stride"], pad=1, ups=cfg["ups"],
+                             rowbias=emb, rowbias_div=Ho * Wo)
+    assert (ho, wo) == (Ho, Wo)
+    check(f"conv3x3 {cfg}", out.reshape(F, Ho, Wo, Co).permute(0, 3, 1, 2), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_out_ncthw_small_n(dev, dtype):
+    from geo4d_amd import ops, pack
+    B, T, H, W, Ci, Co = 2, 3, 6, 5, 64, 16
+    x_nchw = rnd((B * T, Ci, H, W), dev, dtype, 14)
+    w = rnd((Co, Ci, 3, 3), dev, torch.float32, 15, 0.05)
+    b = rnd((Co,), dev, torch.float32, 16)
+    x = x_nchw.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
+    out, _, _ = ops.conv2d(x, pack.pack_conv2d(w, dtype), b, F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, T=T, out_nchw=True)
+    ref = TF.conv2d(x_nchw.float(), w.to(dtype).float(), b, padding=1).reshape(B, T, Co, H, W).permute(0, 2, 1, 3, 4)
+    assert out.shape == (B, Co, T, H, W) and out.dtype == torch.float32
+    check("conv ncthw", out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_temporal(dev, dtype):
+    from geo4d_amd import ops, pack
+    B, T, HW, Cc = 2, 5, 12, 64
+    x5 = rnd((B, Cc, T, HW, 1), dev, dtype, 17)
+    w = rnd((Cc, Cc, 3, 1, 1), dev, torch.float32, 18, 0.08)
+    b = rnd((Cc,), dev, torch.float32, 19)
+    x = x5.permute(0, 2, 3, 4, 1).reshape(B * T * HW, Cc).contiguous()
+    out = ops.conv_temporal(x, pack.pack_conv3d_t(w, dtype), b, B=B, T=T, HW=HW, residual=x)
+    ref = TF.conv3d(x5.float(), w.to(dtype).float(), b, padding=(1, 0, 0)) + x5.float()
+    check("conv3d(3,1,1)", out.reshape(B, T, HW, 1, Cc).permute(0, 4, 1, 2, 3), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batched_gemm_rowbias_alpha(dev, dtype):
+    from geo4d_amd import ops
+    Z, M, N, K = 3, 70, 100, 64
+    a, b = rnd((Z * M, K), dev, dtype, 20), rnd((Z * N, K), dev, dtype, 21)
+    bias = rnd((M,), dev, torch.float32, 22)
+    out = torch.empty((Z * M, N), device=dev, dtype=torch.float32)
+    ops.batched_gemm(a, b, out, batch=Z, M=M, N=N, K=K, a_bs=M * K, b_bs=N * K, o_bs=M * N, bias=bias, bias_per_row=True,
+                     alpha=0.25)
+    ref = 0.25 * torch.einsum("zmk,znk->zmn", a.float().reshape(Z, M, K), b.float().reshape(Z, N, K)) + bias[None, :, None]
+    check("batched gemm", out.reshape(Z, M, N), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(4, 6 * 7, 320, 1), (6, 5 * 4, 64, 3), (2, 70 * 33, 128, 1), (4, 1, 960, 2)])
+def test_groupnorm(dev, dtype, case):
+    from geo4d_amd import ops
+    F, HW, Cc, fps = case
+    x = rnd((F * HW, Cc), dev, dtype, 23) * 2 + 0.7
+    g, b = rnd((Cc,), dev, torch.float32, 24), rnd((Cc,), dev, torch.float32, 25)
+    out = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)
+    x5 = x.float().reshape(F // fps, fps, HW, Cc).permute(0, 3, 1, 2)  # [stat, C, fps, HW]
+    ref = TF.silu(TF.group_norm(x5, 32, g, b, 1e-5)).permute(0, 2, 3, 1).reshape(F * HW, Cc)
+    check(f"groupnorm {case}", out, ref, dtype, scale=2.0)
+    out2 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)
+    assert torch.equal(out, out2), "groupnorm must be run-to-run deterministic"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cc", [320, 640, 1280, 512])
+def test_layernorm(dev, dtype, Cc):
+    from geo4d_amd import ops
+    x = rnd((77, Cc), dev, dtype, 26) * 3 + 1
+    g, b = rnd((Cc,), dev, torch.float32, 27), rnd((Cc,), dev, torch.float32, 28)
+    out = ops.layernorm(x, g, b, 1e-5)
+    check(f"layernorm {Cc}", out, TF.layer_norm(x.float(), (Cc,), g, b, 1e-5), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_rows(dev, dtype):
+    from geo4d_amd import ops
+    x = rnd((50, 333), dev, torch.float32, 29) * 4
+    out = ops.softmax_rows(x, 0.3, dtype)
+    check("softmax", out, torch.softmax(x * 0.3, -1), dtype)
+
+
+def _sdpa(q, k, v, scale):
+    return torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N", [40, 160, 200])
+def test_attention_self(dev, dtype, N):
+    from geo4d_amd import ops
+    B, H = 3, 5
+    qkv = rnd((B * N, 3 * H * 64), dev, dtype, 30)
+    C_ = H * 64
+    out = ops.attention(qkv[:, :C_], [(qkv[:, C_:2 * C_], qkv[:, 2 * C_:], N, 1)], B=B, H=H, Nq=N, scale=0.125)
+    f = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = _sdpa(f[0], f[1], f[2], 0.125).permute(0, 2, 1, 3).reshape(B * N, C_)
+    check(f"attn self N={N}", out, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_cross_two_sets(dev, dtype):
+    """77 text keys shared by all T frames of a sample + 16 per-frame image keys, outputs summed (attention.py:128-142)."""
+    from geo4d_amd import ops
+    Bs, T, N, H = 2, 3, 50, 2
+    C_ = H * 64
+    q = rnd((Bs * T * N, C_), dev, dtype, 31)
+    kt, vt = rnd((Bs * 77, C_), dev, dtype, 32), rnd((Bs * 77, C_), dev, dtype, 33)
+    ki, vi = rnd((Bs * T * 16, C_), dev, dtype, 34), rnd((Bs * T * 16, C_), dev, dtype, 35)
+    out = ops.attention(q, [(kt, vt, 77, T), (ki, vi, 16, 1)], B=Bs * T, H=H, Nq=N, scale=0.125)
+
+    def heads(x, b, n):
+        return x.float().reshape(b, n, H, 64).permute(0, 2, 1, 3)
+    qh = heads(q, Bs * T, N)
+    kth = heads(kt, Bs, 77).repeat_interleave(T, 0)
+    vth = heads(vt, Bs, 77).repeat_interleave(T, 0)
+    ref = _sdpa(qh, kth, vth, 0.125) + _sdpa(qh, heads(ki, Bs * T, 16), heads(vi, Bs * T, 16), 0.125)
+    check("attn cross", out, ref.permute(0, 2, 1, 3).reshape(Bs * T * N, C_), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_online_softmax_rescale(dev, dtype):
+    """A key far above the rest in a LATE tile forces the running-max rescale branch (rule 26)."""
+    from geo4d_amd import ops
+    N, H = 256, 1
+    q, k, v = rnd((N, 64), dev, dtype, 36), rnd((N, 64), dev, dtype, 37), rnd((N, 64), dev, dtype, 38)
+    k[200] = (q[7].float() * 4).to(dtype)
+    out = ops.attention(q, [(k, v, N, 1)], B=1, H=H, Nq=N, scale=0.125)
+    check("attn spike", out, _sdpa(q.float(), k.float(), v.float(), 0.125), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [16, 5])
+def test_temporal_attention(dev, dtype, T):
+    from geo4d_amd import ops
+    B, HW, H = 2, 7, 3
+    C_ = H * 64
+    qkv = rnd((B * T * HW, 3 * C_), dev, dtype, 39)
+    out = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=H, scale=0.125)
+    f = qkv.float().reshape(B, T, HW, 3, H, 64).permute(3, 0, 2, 4, 1, 5)  # [3, B, HW, H, T, 64]
+    ref = _sdpa(f[0], f[1], f[2], 0.125).permute(0, 3, 1, 2, 4).reshape(B * T * HW, C_)
+    check(f"temporal attn T={T}", out, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_and_concat(dev, dtype):
+    from geo4d_amd import ops
+    B, T, H, W = 2, 3, 4, 5
+    a, b = rnd((B, 16, T, H, W), dev, torch.float32, 40), rnd((B, 4, T, H, W), dev, torch.float32, 41)
+    tok = ops.tokens_from_ncthw(a, b, 32, dtype)
+    ref = torch.cat([a, b], 1).permute(0, 2, 3, 4, 1).reshape(-1, 20).to(dtype)
+    assert torch.equal(tok[:, :20], ref) and tok[:, 20:].abs().max().item() == 0
+    x, y = rnd((33, 64), dev, dtype, 42), rnd((33, 128), dev, dtype, 43)
+    assert torch.equal(ops.concat_channels(x, y), torch.cat([x, y], 1))
+
+
+def test_embedding_and_small_linear(dev):
+    from geo4d_amd import ops
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+    t = torch.tensor([999, 19], device=dev, dtype=torch.int64)
+    e = ops.timestep_embedding(t, freqs)
+    args = t[:, None].float() * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert (e - ref).abs().max().item() < 2e-4  # t*freq up to 999 rad: device sin/cos vs torch differ by ulps of the argument
+    w, b = rnd((300, 320), dev, torch.float32, 44, 0.05), rnd((300,), dev, torch.float32, 45)
+    add = rnd((2, 300), dev, torch.float32, 46)
+    out = ops.linear_small(e, w, b, add=add, act_in=True, act_out=True)
+    check("linear_small", out, TF.silu(TF.silu(e) @ w.t() + b) + add, torch.float32)
+
+
+def test_ddim_step(dev):
+    from geo4d_amd import ops
+    x, v, nz = rnd((1000,), dev, torch.float32, 47), rnd((1000,), dev, torch.float32, 48), rnd((1000,), dev, torch.float32, 49)
+    coef = torch.tensor([[0.0] * 6, [0.6, 0.8, 0.9, 0.7, 0.5, 0.1]], device=dev)
+    idx = torch.tensor([1], device=dev, dtype=torch.int32)
+    x0 = torch.empty_like(x)
+    xr = x.clone()
+    ops.ddim_step(x, v, coef, idx, noise=nz, pred_x0=x0)
+    e_t = 0.6 * v + 0.8 * xr
+    p0 = (0.6 * xr - 0.8 * v) * 0.9
+    check("ddim x0", x0, p0, torch.float32)
+    check("ddim x_prev", x, 0.7 * p0 + 0.5 * e_t + 0.1 * nz, torch.float32)
+    ops.advance_index(idx, -1)
+    assert idx.item() == 0
