@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE ITSELF (/root/reference) on CPU.
+
+Run in the build container only (`python tests/golden/generate.py`); the GPU box has no /root/reference and only
+reads the committed .pt files. What is imported from the reference, unmodified:
+  lvdm.models.ddpm3d.LatentDiffusion (schedule, v-param helpers, apply_model, DiffusionWrapper 'hybrid',
+  decode_first_stage), lvdm.modules.networks.openaimodel3d.UNetModel, lvdm.models.samplers.ddim.DDIMSampler,
+  lvdm.models.autoencoder.AutoencoderKL (+ Decoder, VAEDecoderadaptor), utils.utils.instantiate_from_config,
+  and — because scripts/evaluation/test_geo4d.py cannot be imported (decord / omegaconf / pytorch3d absent) — the
+  SOURCE TEXT of its window loop (:417-423), mask helpers (:84-89, :276-287) and post-decode block (:447-503),
+  exec'd verbatim from the file at generation time (never copied into this repo).
+Missing third-party modules are stubbed: cv2 (unused on this path), pytorch_lightning.LightningModule -> nn.Module,
+torchvision.utils.make_grid (logging only). Weights: oracle.params (name-keyed seeded fill), so fixtures hold only
+inputs and outputs.
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle.params import fill_module_  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _LM(nn.Module):
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+_stub("cv2")
+_pl = _stub("pytorch_lightning", LightningModule=_LM)
+_pl.utilities = _stub("pytorch_lightning.utilities", rank_zero_only=lambda f: f)
+_tv = _stub("torchvision")
+_tv.utils = _stub("torchvision.utils", make_grid=None)
+
+
+class AD(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def ad(x):
+    if isinstance(x, dict):
+        return AD({k: ad(v) for k, v in x.items()})
+    if isinstance(x, list):
+        return [ad(v) for v in x]
+    return x
+
+
+def tiny_configs(mc=64, ctx=128, vae_ch=32):
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=vae_ch, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    adp = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=1, ch=vae_ch, ch_mult=[1],
+               num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    unet = dict(in_channels=20, out_channels=16, model_channels=mc, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                channel_mult=[1, 2, 4, 4], dropout=0.1, num_head_channels=64, transformer_depth=1, context_dim=ctx,
+                use_linear=True, use_checkpoint=False, temporal_conv=True, temporal_attention=True,
+                temporal_selfatt_only=True, use_relative_position=False, use_causal_attention=False, temporal_length=16,
+                addition_attention=True, image_cross_attention=True, default_fs=24, fs_condition=True)
+    return unet, dd, adp
+
+
+def build_reference(unet, dd, adp):
+    from lvdm.models.ddpm3d import LatentDiffusion
+    fs = dict(target="lvdm.models.autoencoder.AutoencoderKL",
+              params=dict(embed_dim=4, monitor="val/rec_loss", ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"),
+                          adaptorconfig=adp))
+    m = LatentDiffusion(
+        first_stage_config=ad(fs), cond_stage_config=ad(dict(target="torch.nn.Identity")),
+        unet_config=ad(dict(target="lvdm.modules.networks.openaimodel3d.UNetModel", params=unet)),
+        rescale_betas_zero_snr=True, parameterization="v", linear_start=0.00085, linear_end=0.012, num_timesteps_cond=1,
+        timesteps=1000, modality="pc_ray_cross_depth", first_stage_key="normed_allpts", cond_stage_key="video",
+        cond_stage_trainable=False, conditioning_key="hybrid", image_size=[32, 64], channels=16, scale_by_std=False,
+        scale_factor=0.18215, use_ema=False, uncond_type="empty_seq", use_dynamic_rescale=True, base_scale=0.7,
+        fps_condition_type="fps", perframe_ae=True)
+    m.eval()
+    fill_module_(m.model.diffusion_model)
+    fill_module_(m.first_stage_model)
+    return m
+
+
+def randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def script_source(first, last):
+    with open(os.path.join(REF, "scripts/evaluation/test_geo4d.py")) as f:
+        lines = [l.rstrip("\r\n") + "\n" for l in f.readlines()]   # the script has CRLF line endings
+    return lines[first - 1:last]
+
+
+def script_functions(names):
+    with open(os.path.join(REF, "scripts/evaluation/test_geo4d.py")) as f:
+        src = f.read().replace("\r\n", "\n")
+    tree = ast.parse(src)
+    ns = {"torch": torch}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), "test_geo4d.py", "exec"), ns)
+    return ns
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from lvdm.models.samplers.ddim import DDIMSampler
+
+    class CpuSampler(DDIMSampler):  # ddim.py:18-22 hard-codes torch.device("cuda")
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    unet_cfg, dd, adp = tiny_configs()
+    model = build_reference(unet_cfg, dd, adp)
+    out = {}
+
+    # ---- 1. schedule tables ------------------------------------------------------------------------------
+    sched = dict(alphas_cumprod=model.alphas_cumprod.clone(), betas=model.betas.clone(),
+                 sqrt_alphas_cumprod=model.sqrt_alphas_cumprod.clone(),
+                 sqrt_one_minus_alphas_cumprod=model.sqrt_one_minus_alphas_cumprod.clone(),
+                 alphas_cumprod_prev=model.alphas_cumprod_prev.clone(), scale_arr=model.scale_arr.clone())
+    for S in (5, 50):
+        s = CpuSampler(model)
+        s.make_schedule(ddim_num_steps=S, ddim_discretize="uniform_trailing", ddim_eta=0.0, verbose=False)
+        sched[f"ddim_timesteps_{S}"] = torch.from_numpy(np.ascontiguousarray(s.ddim_timesteps)).long()
+        sched[f"ddim_alphas_{S}"] = torch.as_tensor(np.asarray(s.ddim_alphas), dtype=torch.float32)
+        sched[f"ddim_alphas_prev_{S}"] = torch.as_tensor(np.asarray(s.ddim_alphas_prev, dtype=np.float64), dtype=torch.float64)
+        sched[f"ddim_scale_arr_{S}"] = s.ddim_scale_arr.clone()
+        sched[f"ddim_scale_arr_prev_{S}"] = s.ddim_scale_arr_prev.clone()
+    torch.save(sched, os.path.join(HERE, "schedule.pt"))
+
+    # ---- 2. U-Net forward (reference UNetModel through DiffusionWrapper 'hybrid') -------------------------
+    cases = {}
+    for name, (B, T, h, w) in {"t16_8x8": (1, 16, 8, 8), "b2_t5_8x16": (2, 5, 8, 16)}.items():
+        x = randn((B, 16, T, h, w), 100)
+        cc = randn((B, 4, T, h, w), 101)
+        ctx = randn((B, 77 + 16 * T, unet_cfg["context_dim"]), 102)
+        t = torch.tensor([999, 419][:B], dtype=torch.long)
+        fs = torch.tensor([24, 8][:B], dtype=torch.long)
+        with torch.no_grad():
+            y = model.apply_model(x, t, {"c_crossattn": [ctx], "c_concat": [cc]}, fs=fs, cfg_img=None,
+                                  unconditional_conditioning_img_nonetext=None)
+        cases[name] = dict(x=x, c_concat=cc, context=ctx, t=t, fs=fs, out=y)
+        print("unet", name, tuple(y.shape), float(y.std()))
+    shapes = {k: tuple(v.shape) for k, v in model.model.diffusion_model.state_dict().items()}
+    torch.save(dict(unet_config=unet_cfg, cases=cases, shapes=shapes), os.path.join(HERE, "unet_tiny.pt"))
+
+    # ---- 3. DDIM sampling (reference DDIMSampler driving the reference LatentDiffusion) ------------------
+    B, T, h, w = 1, 16, 8, 8
+    x_T = randn((B, 16, T, h, w), 200)
+    cond = {"c_crossattn": [randn((B, 77 + 16 * T, unet_cfg["context_dim"]), 201)], "c_concat": [randn((B, 4, T, h, w), 202)]}
+    fs = torch.tensor([24], dtype=torch.long)
+    visited = []
+    orig = model.apply_model
+
+    def spy(x, t, c, **kw):
+        visited.append((int(t[0]), sorted(kw.keys())))
+        return orig(x, t, c, **kw)
+    model.apply_model = spy
+    with torch.no_grad():
+        samples, _ = CpuSampler(model).sample(S=4, conditioning=cond, batch_size=B, shape=[16, T, h, w], verbose=False,
+                                              unconditional_guidance_scale=1.0, unconditional_conditioning=None, eta=0.0,
+                                              cfg_img=None, mask=None, x0=None, fs=fs, x_T=x_T,
+                                              timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                              unconditional_conditioning_img_nonetext=None)
+    model.apply_model = orig
+    print("ddim visited", visited, float(samples.std()))
+    ddim = dict(unet_config=unet_cfg, x_T=x_T, context=cond["c_crossattn"][0], c_concat=cond["c_concat"][0], fs=fs, S=4,
+                samples=samples, visited_t=torch.tensor([v[0] for v in visited]), forwarded_kwargs=visited[0][1])
+
+    # ---- 4. VAE decode paths (reference AutoencoderKL) + 4-modality decode of the sampled latent ----------
+    vae = model.first_stage_model
+    z = randn((2, 4, 6, 8), 300)
+    with torch.no_grad():
+        dec = vae.decode(z)
+        dec_conf = vae.decode_with_conf_adaptor(z)
+        ray = model.decode_first_stage(samples[:, 4:8])                  # ddpm3d.py:802-823, perframe_ae=True
+    print("vae", tuple(dec.shape), tuple(dec_conf.shape), tuple(ray.shape))
+    torch.save(dict(ddconfig=dd, adaptorconfig=adp, z=z, decode=dec, decode_with_conf_adaptor=dec_conf,
+                    shapes={k: tuple(v.shape) for k, v in vae.state_dict().items()}), os.path.join(HERE, "vae_tiny.pt"))
+    ddim["decode_first_stage_4_8"] = ray
+    torch.save(ddim, os.path.join(HERE, "ddim_tiny.pt"))
+
+    # ---- 5. window indices + post-decode block: exec the script's own source lines ------------------------
+    win_src = "".join(l[8:] if l.startswith("        ") else l for l in script_source(417, 422))
+    windows = {}
+    for Tn in (16, 17, 19, 20, 50, 64, 128):
+        for stride in (4, 3):
+            ns = {"T": Tn, "args": types.SimpleNamespace(stride=stride)}
+            exec(win_src, ns)
+            windows[(Tn, stride)] = [(s.start, s.stop) for s in ns["slice_list"]]
+    print("windows T=64:", len(windows[(64, 4)]), windows[(64, 4)][-3:])
+
+    fns = script_functions({"get_sky_mask", "get_far_away_mask", "denormalize_pc_bbox2"})
+    from einops import rearrange
+    post_src = "".join(l[12:] if l.startswith("            ") else l for l in script_source(447, 503))
+    Tn, H, W = 16, 12, 10
+    bs = randn((1, 11, Tn, H, W), 400) * 1.2
+    bs[0, 0:3, 2, 3:6, 2:5] = 1.05   # sky pixels
+    bs[0, 0, 5, 0:2, 0:2] = 2.5      # far pixels
+    ns = dict(fns)
+    ns.update(torch=torch, rearrange=rearrange, batch_samples=bs.clone(), model=types.SimpleNamespace(modality="pc_ray_cross_depth"),
+              use_raymap=False, use_crossmap=False, use_inverse_depthmap=True, use_traj=True, pointmap_vae=object(),
+              raymap_to_camera_matrix=lambda r, c: None, pnt_valid_mask=torch.ones((Tn, H, W, 1)) > 0, sl=slice(0, Tn, 1),
+              pred_list=[])
+    exec(post_src, ns)
+    pred = ns["pred_list"][0]
+    post = dict(batch_samples=bs, pts3d=pred["pts3d"], conf=pred["conf"], inverse_depthmap=pred["inverse_depthmap"],
+                pnt_valid_mask=ns["pnt_valid_mask"])
+    print("post", {k: tuple(v.shape) for k, v in post.items()}, int((~ns["pnt_valid_mask"]).sum()))
+    torch.save(dict(windows=windows, post=post), os.path.join(HERE, "glue.pt"))
+
+    # ---- 6. the REAL yaml config: state_dict census + one forward at 8x8 latents ---------------------------------
+    import yaml
+    with open(os.path.join(REF, "configs/inference_geo4d.yaml")) as f:
+        ycfg = yaml.safe_load(f)
+    full_cfg = dict(ycfg["model"]["params"]["unet_config"]["params"])
+    full_cfg["use_checkpoint"] = False   # test_geo4d.py:321-322
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    from lvdm.models.autoencoder import AutoencoderKL
+    full = UNetModel(**full_cfg).eval()
+    fill_module_(full)
+    x = randn((1, 20, 16, 8, 8), 500)
+    ctx = randn((1, 77 + 16 * 16, 1024), 501)
+    with torch.no_grad():
+        y = full(x, torch.tensor([639]), context=ctx, fs=torch.tensor([24]))
+    print("unet full", tuple(y.shape), float(y.std()), sum(p.numel() for p in full.parameters()) / 1e6, "M params")
+    vparams = ycfg["model"]["params"]["first_stage_config"]["params"]
+    with torch.device("meta"):
+        fvae = AutoencoderKL(**{k: (ad(v) if isinstance(v, dict) else v) for k, v in vparams.items()})
+    torch.save(dict(unet_config=full_cfg, x=x, context=ctx, t=torch.tensor([639]), fs=torch.tensor([24]), out=y,
+                    shapes={k: tuple(v.shape) for k, v in full.state_dict().items()},
+                    vae_shapes={k: tuple(v.shape) for k, v in fvae.state_dict().items()},
+                    ddconfig=vparams["ddconfig"], adaptorconfig=vparams["adaptorconfig"]),
+               os.path.join(HERE, "unet_full.pt"))
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".pt"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
