@@ -21,7 +21,7 @@ class ConvGemm(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("W", C.c_void_p), ("O", C.c_void_p),
         ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("R", C.c_void_p),
-        ("lda", C.c_long), ("ldw", C.c_long), ("ldo", C.c_long), ("ldr", C.c_long),
+        ("lda", C.c_long), ("ldw", C.c_long), ("ldo", C.c_long), ("ldr", C.c_long), ("ldrb", C.c_long),
         ("a_bs", C.c_long), ("w_bs", C.c_long), ("o_bs", C.c_long), ("r_bs", C.c_long),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
         ("Cin", C.c_int),
@@ -78,6 +78,7 @@ SIGNATURES = {
     "geo4d_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                   C.c_void_p]),
     "geo4d_advance_index": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "geo4d_gather_timestep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_last_error": (C.c_char_p, []),
     "geo4d_abi_version": (C.c_int, []),
 }

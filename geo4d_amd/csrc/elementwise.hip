@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ x, c
 }
 
 __global__ void advance_index_kernel(int* idx, int delta) { *idx += delta; }
+__global__ void gather_timestep_kernel(const int* idx, const long* table, long* ts, int B) {
+    const int b = threadIdx.x;
+    if (b < B) ts[b] = table[*idx];
+}
 
 }  // namespace
 
@@ -175,6 +179,13 @@ extern "C" int geo4d_ddim_step(float* x, const float* v, const float* noise, flo
 extern "C" int geo4d_advance_index(int* idx, int delta, void* stream) {
     if (!idx) return GEO4D_EINVAL;
     hipLaunchKernelGGL(advance_index_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, idx, delta);
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
+extern "C" int geo4d_gather_timestep(const int* idx, const long* table, long* ts, int B, void* stream) {
+    if (!idx || !table || !ts || B <= 0 || B > 1024) { geo4d_set_error("gather_timestep: bad arguments"); return GEO4D_EINVAL; }
+    hipLaunchKernelGGL(gather_timestep_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, table, ts, B);
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;
 }

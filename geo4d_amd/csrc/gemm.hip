@@ -205,13 +205,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
             const int row = row_w0 + a * 32 + acc_row(r, g);
             if (row >= p.M) continue;
             const float brow = (p.bias && p.bias_per_row) ? p.bias[row] : 0.f;
-            const long rboff = p.rowbias ? (long)(row / p.rowbias_div) * p.N : 0;
+            const long rboff = p.rowbias ? (long)(row / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
             long obase_row, ostride_col;
             if (p.out_nchw) {
                 // [B][N][T][hw]  (T = 1 gives plain NCHW per frame)
                 const int f = row / hw;
                 const int bb = f / p.T, tt = f - bb * p.T;
-                obase_row = ((long)bb * p.N * p.T + tt) * hw + (row - f * hw);
+                obase_row = ((long)bb * p.ldo * p.T + tt) * hw + (row - f * hw);  // ldo = channels of the NCTHW tensor
                 ostride_col = (long)p.T * hw;
             } else {
                 obase_row = (long)row * p.ldo;

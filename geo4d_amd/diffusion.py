@@ -1,0 +1,159 @@
+"""Latent diffusion glue — the slice of ``lvdm.models.ddpm3d`` that inference touches, rebuilt around
+the HIP U-Net and VAE: noise schedule (register_schedule, ddpm3d.py:162-225), v-parameterisation helpers (:278-290),
+dynamic-rescale table (:585-590), ``apply_model`` (:1002-1017), ``DiffusionWrapper`` 'hybrid' (:2529-2544) and
+``decode_first_stage`` / ``decode_core`` (:802-823, 935-936). Class and attribute names follow the reference so that
+``scripts/evaluation/test_geo4d.py`` style code (``model.model.diffusion_model.out_channels``, ``model.scale_factor``,
+``model.perframe_ae``, ``model.decode_first_stage`` ...) works unchanged. The ~2400 training / logging lines of the
+reference class are out of scope.
+
+The conditioning encoders (OpenCLIP text/image + Resampler, VAE encode) are SURVEY.md §8(f) N3: they are not instantiated;
+``get_learned_conditioning`` / ``embedder`` / ``encode_first_stage`` raise unless a caller injects precomputed tensors.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .registry import instantiate_from_config
+
+
+class DiffusionWrapper(nn.Module):
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+
+    def forward(self, x, t, c_concat=None, c_crossattn=None, **kwargs):
+        if self.conditioning_key != "hybrid":
+            raise NotImplementedError(f"conditioning_key={self.conditioning_key!r}: Geo4D inference uses 'hybrid' only")
+        cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+        extra = c_concat[0] if len(c_concat) == 1 else torch.cat(c_concat, 1)
+        # the channel concat of ddpm3d.py:2542 happens inside the token-layout kernel (two sources)
+        return self.diffusion_model(x, t, context=cc, c_concat=extra, **kwargs)
+
+
+def _beta_schedule(n, linear_start, linear_end, zero_snr):
+    betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n, dtype=torch.float64, device="cpu") ** 2).numpy()
+    if zero_snr:  # utils_diffusion.py:112-144
+        s = np.sqrt(np.cumprod(1.0 - betas, axis=0))
+        s0, sT = s[0].copy(), s[-1].copy()
+        s = (s - sT) * (s0 / (s0 - sT))
+        abar = s ** 2
+        betas = 1 - np.concatenate([abar[0:1], abar[1:] / abar[:-1]])
+    return betas
+
+
+class LatentDiffusion(nn.Module):
+    def __init__(self, unet_config, first_stage_config=None, cond_stage_config=None, timesteps=1000, beta_schedule="linear",
+                 linear_start=1e-4, linear_end=2e-2, parameterization="eps", conditioning_key=None,
+                 rescale_betas_zero_snr=False, scale_factor=1.0, scale_by_std=False, use_dynamic_rescale=False,
+                 base_scale=0.7, turning_step=400, perframe_ae=False, encoder_type="2d", modality="rgb",
+                 uncond_type="empty_seq", channels=3, image_size=256, first_stage_key="image", cond_stage_key="caption",
+                 use_ema=False, **ignored):
+        super().__init__()
+        if beta_schedule != "linear":
+            raise NotImplementedError("only the 'linear' beta schedule of the Geo4D config is built")
+        self.parameterization = parameterization
+        self.model = DiffusionWrapper(unet_config, conditioning_key or "crossattn")
+        self.first_stage_model = instantiate_from_config(first_stage_config) if first_stage_config is not None else None
+        self.cond_stage_model = None      # N3: OpenCLIP text encoder not built
+        self.cond_stage_config = cond_stage_config
+        self.scale_factor, self.scale_by_std = scale_factor, scale_by_std
+        self.use_dynamic_rescale, self.perframe_ae, self.encoder_type = use_dynamic_rescale, perframe_ae, encoder_type
+        self.modality, self.uncond_type, self.channels, self.image_size = modality, uncond_type, channels, image_size
+        self.first_stage_key, self.cond_stage_key = first_stage_key, cond_stage_key
+        self.cross_attention = False      # LatentVisualDiffusion default (ddpm3d.py:1333): conditioning image is zeroed
+        self.temporal_length = unet_config["params"].get("temporal_length")
+        betas = _beta_schedule(timesteps, linear_start, linear_end, rescale_betas_zero_snr)
+        ac = np.cumprod(1.0 - betas, axis=0)
+        f32 = lambda a: torch.tensor(a, dtype=torch.float32, device="cpu")
+        self.num_timesteps = int(timesteps)
+        self.register_buffer("betas", f32(betas))
+        self.register_buffer("alphas_cumprod", f32(ac))
+        self.register_buffer("alphas_cumprod_prev", f32(np.append(1.0, ac[:-1])))
+        self.register_buffer("sqrt_alphas_cumprod", f32(np.sqrt(ac)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", f32(np.sqrt(1.0 - ac)))
+        if use_dynamic_rescale:
+            arr = np.concatenate((np.linspace(1.0, base_scale, turning_step), np.full(self.num_timesteps, base_scale)))
+            self.register_buffer("scale_arr", f32(arr))
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    # ---- v-parameterisation (ddpm3d.py:278-290) -------------------------------------------------------------------
+    def _gather(self, a, t, x):
+        return a.gather(-1, t).reshape(t.shape[0], *((1,) * (x.dim() - 1)))
+
+    def predict_start_from_z_and_v(self, x_t, t, v):
+        return self._gather(self.sqrt_alphas_cumprod, t, x_t) * x_t - self._gather(self.sqrt_one_minus_alphas_cumprod, t, x_t) * v
+
+    def predict_eps_from_z_and_v(self, x_t, t, v):
+        return self._gather(self.sqrt_alphas_cumprod, t, x_t) * v + self._gather(self.sqrt_one_minus_alphas_cumprod, t, x_t) * x_t
+
+    # ---- denoiser (ddpm3d.py:1002-1017) -------------------------------------------------------------------------------
+    def apply_model(self, x_noisy, t, cond, **kwargs):
+        if not isinstance(cond, dict):
+            cond = {"c_crossattn": cond if isinstance(cond, list) else [cond]}
+        out = self.model(x_noisy, t, **cond, **kwargs)
+        return out[0] if isinstance(out, tuple) else out
+
+    # ---- first stage (ddpm3d.py:802-870, 935-936) -----------------------------------------------------------------
+    def _decode(self, fn, z):
+        reshape_back = self.encoder_type == "2d" and z.dim() == 5
+        if reshape_back:
+            b, c, t, h, w = z.shape
+            z = z.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+        out = fn(z * (1.0 / self.scale_factor))       # all frames in one batch: identical to the per-frame loop
+        if reshape_back:
+            out = out.reshape(b, t, *out.shape[1:]).permute(0, 2, 1, 3, 4)
+        return out
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, **kwargs):
+        return self._decode(self.first_stage_model.decode, z)
+
+    decode_core = differentiable_decode_first_stage = decode_first_stage
+
+    @torch.no_grad()
+    def decode_first_stage_confhead(self, z, **kwargs):
+        return self._decode(self.first_stage_model.decode_with_conf_adaptor, z)
+
+    decode_core_confhead = decode_first_stage_confhead
+
+    # ---- conditioning front-end: N3 -----------------------------------------------------------------------------------
+    def _n3(self, what):
+        raise NotImplementedError(f"{what}: the conditioning front-end (OpenCLIP text/image encoders, Resampler, VAE encode) is "
+                                  "SURVEY.md §8(f) N3 and is not built; pass precomputed `cond` tensors instead")
+
+    def get_learned_conditioning(self, c):
+        self._n3("get_learned_conditioning")
+
+    def encode_first_stage(self, x):
+        self._n3("encode_first_stage")
+
+    def embedder(self, x):
+        self._n3("embedder")
+
+    def image_proj_model(self, x):
+        self._n3("image_proj_model")
+
+    # ---- checkpoints (test_geo4d.py:54-81): reference keys model.diffusion_model.* / first_stage_model.* ---------
+    def load_reference_state_dict(self, state_dict):
+        sd = state_dict.get("state_dict", state_dict)
+        own = self.state_dict()
+        picked = {k: v for k, v in sd.items() if k in own}
+        missing = [k for k in own if k not in picked]
+        if missing:
+            raise KeyError(f"checkpoint lacks {len(missing)} tensors of the hot path, e.g. {missing[:3]}")
+        skipped = sorted({k.split(".")[0] for k in sd if k not in own})
+        self.load_state_dict(picked, strict=True)
+        return skipped   # e.g. ['cond_stage_model', 'embedder', 'image_proj_model']: N3 components
+
+
+class LatentVisualDiffusion(LatentDiffusion):
+    """yaml ``model.target`` (configs/inference_geo4d.yaml:40); img_cond_stage_config / image_proj_stage_config are N3."""
+
+    def __init__(self, img_cond_stage_config=None, image_proj_stage_config=None, freeze_embedder=True,
+                 image_proj_model_trainable=True, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.img_cond_stage_config, self.image_proj_stage_config = img_cond_stage_config, image_proj_stage_config

@@ -61,7 +61,8 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
     if rowbias is not None:
-        assert rowbias.dtype == torch.float32 and rowbias.is_contiguous()
+        assert rowbias.dtype == torch.float32 and rowbias.dim() == 2 and rowbias.stride(1) == 1
+        p.ldrb = rowbias.stride(0)
     if residual is not None:
         assert residual.dtype == out.dtype
     p.lda, p.ldw, p.ldo, p.ldr = lda, ldw, ldo, ldr
@@ -89,8 +90,9 @@ def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, a
 
 
 def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, ups=1, T=1, rowbias=None, rowbias_div=0,
-           residual=None, act=0, out=None, out_dtype=None, out_nchw=False, tile_hint=0):
-    """x tokens [F*Hin*Win, Cin]; w packed [N, KH*KW*Cin]. Output tokens [F*Hout*Wout, N] (or NCTHW fp32/..)."""
+           residual=None, act=0, out=None, out_dtype=None, out_nchw=False, nchw_channels=None, tile_hint=0):
+    """x tokens [F*Hin*Win, Cin]; w packed [N, KH*KW*Cin]. Output tokens [F*Hout*Wout, N], or with out_nchw a
+    [B, C, T, Hout, Wout] tensor (`out` may be a channel-offset view of a wider tensor with `nchw_channels` channels)."""
     Cin = x.shape[1]
     N = w.shape[0]
     Hs, Ws = Hin * ups, Win * ups
@@ -104,7 +106,7 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, ups=1, T=1, rowb
             out = torch.empty((F // T, N, T, Hout, Wout), device=x.device, dtype=out_dtype or torch.float32)
         else:
             out = torch.empty((M, N), device=x.device, dtype=out_dtype or x.dtype)
-    conv_gemm(x, w, out, M=M, N=N, K=KH * KW * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=N if out_nchw else _ld(out), T=T,
+    conv_gemm(x, w, out, M=M, N=N, K=KH * KW * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=(nchw_channels or N) if out_nchw else _ld(out), T=T,
               Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=KH, KW=KW, ph=pad, pw=pad, stride=stride, ups=ups, bias=bias,
               rowbias=rowbias, rowbias_div=rowbias_div, residual=residual,
               ldr=_ld(residual) if residual is not None else 0, act=act, out_nchw=out_nchw, tile_hint=tile_hint)
@@ -271,3 +273,12 @@ def ddim_step(x, v, coef, step_index, noise=None, pred_x0=None):
 def advance_index(idx, delta):
     lib = _lib.load()
     _lib.check(lib.geo4d_advance_index(idx.data_ptr(), delta, _stream()), "geo4d_advance_index")
+
+
+def gather_timestep(idx, table, ts):
+    """ts[:] = table[idx] on the device (idx int32[1], table int64[S], ts int64[B])."""
+    lib = _lib.load()
+    assert idx.dtype == torch.int32 and table.dtype == torch.int64 and ts.dtype == torch.int64
+    _lib.check(lib.geo4d_gather_timestep(idx.data_ptr(), table.data_ptr(), ts.data_ptr(), ts.numel(), _stream()),
+               "geo4d_gather_timestep")
+    return ts

@@ -1,0 +1,125 @@
+"""Per-window inference glue — the slice of ``scripts/evaluation/test_geo4d.py`` on the hot path:
+window index generation (:417-423), ``image_guided_synthesis`` (:118-274), ``decode_pm_confhead`` (:291-312), the
+4-modality decode (:248-258) and the post-decode tensor math (:446-501). File / video I/O, CLIP conditioning and the
+global alignment are out of scope here.
+"""
+import torch
+import torch.nn.functional as F
+
+from .ddim import DDIMSampler
+
+
+def window_slices(T, stride=4, length=16):
+    """test_geo4d.py:417-423. The reference tests ``slice(T-16, T) not in slice_list`` against entries built as
+    ``slice(start, start+16, 1)``; ``slice(a, b) != slice(a, b, 1)``, so the tail window is ALWAYS appended — and is a
+    duplicate whenever (T-16) % stride == 0 (T = 64 -> 14 windows, last two both (48, 64)). Reproduced bit-exactly."""
+    out = [slice(s, s + length, 1) for s in range(0, T - length + 1, stride)]
+    out.append(slice(T - length, T, 1))
+    return out
+
+
+@torch.no_grad()
+def decode_pm_confhead(z, model, pointmap_vae):
+    """test_geo4d.py:291-312 — point map + confidence through the fine-tuned VAE; frames batched, not looped."""
+    reshape_back = model.encoder_type == "2d" and z.dim() == 5
+    if reshape_back:
+        b, c, t, h, w = z.shape
+        z = z.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+    out = pointmap_vae.decode_with_conf_adaptor(z * (1.0 / model.scale_factor))
+    if reshape_back:
+        out = out.reshape(b, t, *out.shape[1:]).permute(0, 2, 1, 3, 4)
+    return out
+
+
+@torch.no_grad()
+def decode_modalities(model, samples, pointmap_vae=None):
+    """samples [B,16,T,h,w] -> [B,11,T,H,W] = xyz+conf | ray | cross | mean depth (test_geo4d.py:248-258).
+
+    MI355X path: the three modalities that share the first-stage decoder go through it as ONE batch of 3*B*T frames, the
+    per-modality heads write straight into their channel range of the NCTHW result, and the depth channel mean is folded
+    into the head's weights (exact: the head is linear)."""
+    b, c, t, h, w = samples.shape
+    assert c == 16 and model.modality == "pc_ray_cross_depth"
+    vae = model.first_stage_model
+    pvae = pointmap_vae if pointmap_vae is not None else vae
+    inv = 1.0 / model.scale_factor
+
+    def frames(z):
+        return (z.permute(0, 2, 1, 3, 4).reshape(b * t, 4, h, w) * inv).contiguous()
+
+    H, W = 8 * h, 8 * w
+    out = torch.empty((b, 11, t, H, W), device=samples.device, dtype=torch.float32)
+    # point map + confidence
+    feat, _, _ = pvae.decoder_features(frames(samples[:, 0:4]))
+    Pp = pvae._packed
+    pvae._head(Pp["head"], feat, b * t, H, W, out[:, 0:], t, 11)
+    pvae._head(Pp["adaptor_head"], pvae._conf(Pp, feat, b * t, H, W), b * t, H, W, out[:, 3:], t, 11)
+    # ray | cross | depth share the first-stage decoder: one 3*B*T-frame batch through the trunk
+    z3 = torch.cat([frames(samples[:, 4:8]), frames(samples[:, 8:12]), frames(samples[:, 12:16])], 0)
+    feat, _, _ = vae.decoder_features(z3)
+    Pv = vae._packed
+    n = b * t * H * W
+    vae._head(Pv["head"], feat[0:n], b * t, H, W, out[:, 4:], t, 11)
+    vae._head(Pv["head"], feat[n:2 * n], b * t, H, W, out[:, 7:], t, 11)
+    vae._head(Pv["head_mean"], feat[2 * n:3 * n], b * t, H, W, out[:, 10:], t, 11)
+    return out
+
+
+@torch.no_grad()
+def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddim_steps=50, ddim_eta=1.,
+                           unconditional_guidance_scale=1.0, cfg_img=None, fs=None, text_input=False,
+                           multiple_cond_cfg=False, loop=False, interp=False, timestep_spacing='uniform',
+                           guidance_rescale=0.0, pointmap_vae=None, cond=None, x_T=None, **kwargs):
+    """test_geo4d.py:118-274 for modality 'pc_ray_cross_depth'. ``cond`` = {"c_crossattn": [ctx [B,77+16T,1024]],
+    "c_concat": [z_video [B,4,T,h,w]]} must be supplied (the CLIP / VAE-encode front-end is N3). Returns
+    [B, n_samples, 11, T, H, W] like the reference."""
+    if multiple_cond_cfg or loop or interp:
+        raise NotImplementedError("multiple_cond_cfg / loop / interp are outside the shipped Geo4D inference settings")
+    batch_size = noise_shape[0]
+    fs_t = torch.tensor([fs] * batch_size, dtype=torch.long, device=model.device)
+    if cond is None:
+        model.get_learned_conditioning(prompts)       # raises: N3
+    uc = None
+    if unconditional_guidance_scale != 1.0:
+        uc = kwargs.pop("unconditional_conditioning", None)
+        if uc is None:
+            raise NotImplementedError("CFG needs precomputed unconditional conditioning (front-end is N3)")
+    kwargs.update({"unconditional_conditioning_img_nonetext": None})
+    sampler = DDIMSampler(model)
+    variants = []
+    for _ in range(n_samples):
+        samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:], verbose=False,
+                                    unconditional_guidance_scale=unconditional_guidance_scale, unconditional_conditioning=uc,
+                                    eta=ddim_eta, cfg_img=cfg_img, mask=None, x0=None, fs=fs_t, x_T=x_T,
+                                    timestep_spacing=timestep_spacing, guidance_rescale=guidance_rescale, **kwargs)
+        variants.append(decode_modalities(model, samples, pointmap_vae))
+    return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)
+
+
+def get_sky_mask(x, sky_value=1.05, eps=0.05):
+    lo, hi = sky_value - eps, sky_value + eps
+    return ((x > lo) & (x < hi)).all(dim=-1, keepdim=True)
+
+
+def get_far_away_mask(x, far_away_value=1.5):
+    return (x.abs() > far_away_value).any(dim=-1, keepdim=True)
+
+
+def denormalize_pc_bbox2(pc, alpha=1.0, beta=1.0):
+    return torch.stack([pc[..., 0] / alpha, pc[..., 1] / beta, (pc[..., 2] + 1) / 2], dim=-1)
+
+
+@torch.no_grad()
+def postprocess_window(batch_samples, pointmap_vae_used=True):
+    """test_geo4d.py:446-501: [1,11,T,H,W] -> dict(pts3d [T,H,W,3], conf (inverse confidence) [T,H,W,1],
+    inverse_depthmap, raymap, crossmap, valid mask)."""
+    x = batch_samples[0].permute(1, 2, 3, 0)                      # t h w c
+    raymap, crossmap = x[..., 4:7], x[..., 7:10]
+    inverse_depthmap = (x[..., 10:11] + 1.0) / 2.0
+    conf = F.softplus(x[..., 3:4]) if pointmap_vae_used else torch.ones_like(x[..., 3:4])
+    pts = x[..., 0:3]
+    invalid = get_sky_mask(pts, sky_value=1.05, eps=0.35) | get_far_away_mask(pts, far_away_value=1.99)
+    conf = torch.where(invalid, torch.full_like(conf, 999.0), conf)
+    inv_conf = torch.where(invalid, torch.zeros_like(conf), 1.0 / conf)
+    return dict(pts3d=denormalize_pc_bbox2(pts, alpha=2.0, beta=2.0), conf=inv_conf, inverse_depthmap=inverse_depthmap,
+                raymap=raymap, crossmap=crossmap, valid=~invalid)

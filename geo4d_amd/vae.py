@@ -1,0 +1,275 @@
+"""MI355X-native KL-VAE decode — drop-in for ``lvdm.models.autoencoder.AutoencoderKL`` (yaml ``first_stage_config.target``
+and ``pointmap_vae_config.target``, configs/inference_geo4d.yaml:2-37,95-130).
+
+Same constructor (``ddconfig, lossconfig, embed_dim, adaptorconfig, ...``), same ``state_dict`` keys (``encoder.* decoder.*
+quant_conv.* post_quant_conv.* encoder_adaptor.* decoder_adaptor.*`` — strict load as test_geo4d.py:340-347), and the
+decode call surface of the hot path: ``decode(z)`` (autoencoder.py:136-139) and ``decode_with_conf_adaptor(z)``
+(autoencoder.py:120-127). The decoder (ae_modules.py:583-702: conv_in, mid ResnetBlock/AttnBlock/ResnetBlock, 4 up levels
+with nearest-2x upsample convs, GroupNorm(32, eps 1e-6)+swish heads) and the confidence adaptor
+(autoencoder_adaptor.py:203-317) run as HIP kernels on channels-last tokens; all frames handed to one call are decoded
+as one batch (the reference's ``perframe_ae`` loop, ddpm3d.py:810-819, gives identical results frame by frame).
+
+The encode side (``encode`` / ``encoder_adaptor``) is SURVEY.md §8(f) N3 ("next"): its parameters are held for
+state_dict compatibility, calling it raises.
+"""
+import torch
+
+from . import ops, pack
+from .unet import ParamTree, init_params_, resolve_dtype
+
+
+def _resnet_shapes(add, p, cin, cout):
+    add(p + ".norm1.weight", (cin,)); add(p + ".norm1.bias", (cin,))
+    add(p + ".conv1.weight", (cout, cin, 3, 3)); add(p + ".conv1.bias", (cout,))
+    add(p + ".norm2.weight", (cout,)); add(p + ".norm2.bias", (cout,))
+    add(p + ".conv2.weight", (cout, cout, 3, 3)); add(p + ".conv2.bias", (cout,))
+    if cin != cout:
+        add(p + ".nin_shortcut.weight", (cout, cin, 1, 1)); add(p + ".nin_shortcut.bias", (cout,))
+
+
+def _attn_shapes(add, p, c):
+    add(p + ".norm.weight", (c,)); add(p + ".norm.bias", (c,))
+    for n in ("q", "k", "v", "proj_out"):
+        add(f"{p}.{n}.weight", (c, c, 1, 1)); add(f"{p}.{n}.bias", (c,))
+
+
+def decoder_plan(dd):
+    """[(kind, prefix, cin, cout)] in execution order (ae_modules.py:661-702)."""
+    ch, mult, nres = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
+    block_in = ch * mult[-1]
+    plan = [("res", "decoder.mid.block_1", block_in, block_in), ("attn", "decoder.mid.attn_1", block_in, block_in),
+            ("res", "decoder.mid.block_2", block_in, block_in)]
+    for lvl in reversed(range(len(mult))):
+        block_out = ch * mult[lvl]
+        for b in range(nres + 1):
+            plan.append(("res", f"decoder.up.{lvl}.block.{b}", block_in, block_out))
+            block_in = block_out
+        if lvl != 0:
+            plan.append(("up", f"decoder.up.{lvl}.upsample.conv", block_in, block_in))
+    return plan, block_in
+
+
+class AutoencoderKL(ParamTree):
+    def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
+                 colorize_nlabels=None, monitor=None, test=False, logdir=None, input_dim=4, test_args=None,
+                 adaptorconfig=None, compute_dtype=None):
+        super().__init__()
+        dd = dict(ddconfig)
+        assert dd["double_z"]
+        if dd.get("attn_resolutions") or dd.get("upsample_uv") or dd.get("tanh_out") or dd.get("use_linear_attn"):
+            raise NotImplementedError("geo4d_amd.AutoencoderKL: attn_resolutions / upsample_uv / tanh_out / linear attention "
+                                      "are not used by configs/inference_geo4d.yaml and have no HIP path")
+        self.ddconfig, self.adaptorconfig = dd, (dict(adaptorconfig) if adaptorconfig is not None else None)
+        self.embed_dim, self.image_key, self.monitor = embed_dim, image_key, monitor
+        self.compute_dtype = resolve_dtype(compute_dtype)
+        ch, mult, nres, zc = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"], dd["z_channels"]
+        add = self.insert
+        # ---- encoder (held for strict state_dict loading only) --------------------------------------------
+        add("encoder.conv_in.weight", (ch, dd["in_channels"], 3, 3)); add("encoder.conv_in.bias", (ch,))
+        cin = ch
+        for lvl, m in enumerate(mult):
+            for b in range(nres):
+                _resnet_shapes(add, f"encoder.down.{lvl}.block.{b}", cin, ch * m)
+                cin = ch * m
+            if lvl != len(mult) - 1:
+                add(f"encoder.down.{lvl}.downsample.conv.weight", (cin, cin, 3, 3)); add(f"encoder.down.{lvl}.downsample.conv.bias", (cin,))
+        _resnet_shapes(add, "encoder.mid.block_1", cin, cin)
+        _attn_shapes(add, "encoder.mid.attn_1", cin)
+        _resnet_shapes(add, "encoder.mid.block_2", cin, cin)
+        add("encoder.norm_out.weight", (cin,)); add("encoder.norm_out.bias", (cin,))
+        add("encoder.conv_out.weight", (2 * zc, cin, 3, 3)); add("encoder.conv_out.bias", (2 * zc,))
+        # ---- decoder ------------------------------------------------------------------------------------------
+        self.plan, self.feat_ch = decoder_plan(dd)
+        block_in = ch * mult[-1]
+        add("decoder.conv_in.weight", (block_in, zc, 3, 3)); add("decoder.conv_in.bias", (block_in,))
+        for kind, p, ci, co in self.plan:
+            if kind == "res":
+                _resnet_shapes(add, p, ci, co)
+            elif kind == "attn":
+                _attn_shapes(add, p, ci)
+            else:
+                add(p + ".weight", (co, ci, 3, 3)); add(p + ".bias", (co,))
+        add("decoder.norm_out.weight", (self.feat_ch,)); add("decoder.norm_out.bias", (self.feat_ch,))
+        k = dd.get("last_conv_size", 3)
+        if k != 3:
+            raise NotImplementedError("last_conv_size != 3")
+        add("decoder.conv_out.weight", (dd["out_ch"], self.feat_ch, 3, 3)); add("decoder.conv_out.bias", (dd["out_ch"],))
+        add("quant_conv.weight", (2 * embed_dim, 2 * zc, 1, 1)); add("quant_conv.bias", (2 * embed_dim,))
+        add("post_quant_conv.weight", (zc, embed_dim, 1, 1)); add("post_quant_conv.bias", (zc,))
+        # ---- adaptors (autoencoder_adaptor.py:92-199, 203-317) ---------------------------------------------
+        if self.adaptorconfig is not None:
+            ad = self.adaptorconfig
+            assert len(ad["ch_mult"]) == 1
+            ach = ad["ch"] * ad["ch_mult"][0]
+            add("encoder_adaptor.conv_in.weight", (ad["ch"], ad["in_channels"], 3, 3)); add("encoder_adaptor.conv_in.bias", (ad["ch"],))
+            for b in range(ad["num_res_blocks"]):
+                _resnet_shapes(add, f"encoder_adaptor.down.0.block.{b}", ad["ch"] if b == 0 else ach, ach)
+            add("encoder_adaptor.norm_out.weight", (ach,)); add("encoder_adaptor.norm_out.bias", (ach,))
+            add("encoder_adaptor.conv_out.weight", (ad["in_channels"], ach, 3, 3)); add("encoder_adaptor.conv_out.bias", (ad["in_channels"],))
+            for b in range(ad["num_res_blocks"] + 1):
+                _resnet_shapes(add, f"decoder_adaptor.up.0.block.{b}", ach, ach)
+            add("decoder_adaptor.norm_out.weight", (ach,)); add("decoder_adaptor.norm_out.bias", (ach,))
+            add("decoder_adaptor.conv_out.weight", (ad["out_ch"], ach, 3, 3)); add("decoder_adaptor.conv_out.bias", (ad["out_ch"],))
+        init_params_(self)
+        self._packed = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+        if ckpt_path is not None:
+            sd = torch.load(ckpt_path, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            sd = {k: v for k, v in sd.items() if not any(k.startswith(i) for i in ignore_keys)}
+            self.load_state_dict(sd, strict=False)
+
+    def invalidate(self):
+        self._packed = None
+
+    def set_compute_dtype(self, d):
+        self.compute_dtype = resolve_dtype(d)
+        self.invalidate()
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    # ---- packing -----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _pack(self):
+        sd = dict(self.named_parameters())
+        dev = sd["decoder.conv_in.weight"].device
+        if dev.type != "cuda":
+            raise ops._lib.Geo4DNativeError("geo4d_amd.AutoencoderKL runs only on a HIP device: call .cuda() first "
+                                            "(there is no CPU fallback)")
+        ops._lib.load()
+        dt = self.compute_dtype
+        ka = ops.k_align(dt)
+        f32 = lambda n: sd[n].float().contiguous()
+        norm = lambda p: (f32(p + ".weight"), f32(p + ".bias"))
+        P = {}
+        zc = self.ddconfig["z_channels"]
+        # post_quant_conv: N padded to one K slab so its output feeds conv_in directly
+        wq = torch.zeros((ka, ka), device=dev)
+        wq[:zc, : self.embed_dim] = sd["post_quant_conv.weight"].reshape(zc, self.embed_dim)
+        bq = torch.zeros((ka,), device=dev)
+        bq[:zc] = sd["post_quant_conv.bias"]
+        P["pq"] = (wq.to(dt).contiguous(), bq.contiguous())
+        P["cpad"] = ka
+        P["conv_in"] = (pack.pack_conv2d(sd["decoder.conv_in.weight"], dt, cin_pad=ka), f32("decoder.conv_in.bias"))
+
+        def resnet(p):
+            e = dict(gn1=norm(p + ".norm1"), gn2=norm(p + ".norm2"),
+                     c1=(pack.pack_conv2d(sd[p + ".conv1.weight"], dt), f32(p + ".conv1.bias")),
+                     c2=(pack.pack_conv2d(sd[p + ".conv2.weight"], dt), f32(p + ".conv2.bias")))
+            if (p + ".nin_shortcut.weight") in sd:
+                e["nin"] = (pack.pack_linear(sd[p + ".nin_shortcut.weight"], dt), f32(p + ".nin_shortcut.bias"))
+            return e
+        for kind, p, ci, co in self.plan:
+            if kind == "res":
+                P[p] = resnet(p)
+            elif kind == "attn":
+                P[p] = dict(norm=norm(p + ".norm"),
+                            qk=(pack.pack_linear(torch.cat([sd[p + ".q.weight"], sd[p + ".k.weight"]], 0), dt),
+                                torch.cat([sd[p + ".q.bias"], sd[p + ".k.bias"]]).float().contiguous()),
+                            v=(pack.pack_linear(sd[p + ".v.weight"], dt), f32(p + ".v.bias")),
+                            o=(pack.pack_linear(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias")))
+            else:
+                P[p] = (pack.pack_conv2d(sd[p + ".weight"], dt), f32(p + ".bias"))
+        P["head"] = (norm("decoder.norm_out"), pack.pack_conv2d(sd["decoder.conv_out.weight"], dt), f32("decoder.conv_out.bias"))
+        # channel-mean head: mean_c(conv(x, W)_c + b_c) == conv(x, mean_c W_c) + mean_c b_c  (depth modality, test_geo4d.py:254-257)
+        P["head_mean"] = (P["head"][0], pack.pack_conv2d(sd["decoder.conv_out.weight"].mean(0, keepdim=True), dt),
+                          sd["decoder.conv_out.bias"].mean().reshape(1).float().contiguous())
+        if self.adaptorconfig is not None:
+            nb = self.adaptorconfig["num_res_blocks"] + 1
+            P["adaptor"] = [resnet(f"decoder_adaptor.up.0.block.{b}") for b in range(nb)]
+            P["adaptor_head"] = (norm("decoder_adaptor.norm_out"), pack.pack_conv2d(sd["decoder_adaptor.conv_out.weight"], dt),
+                                 f32("decoder_adaptor.conv_out.bias"))
+        self._packed = P
+        return P
+
+    # ---- kernels -------------------------------------------------------------------------------------------------
+    def _resnet(self, e, x, F_, H, W):
+        a = ops.groupnorm(x, *e["gn1"], F=F_, HW=H * W, eps=1e-6, silu=True)
+        h, _, _ = ops.conv2d(a, *e["c1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1)
+        a = ops.groupnorm(h, *e["gn2"], F=F_, HW=H * W, eps=1e-6, silu=True)
+        skip = ops.linear(x, *e["nin"]) if "nin" in e else x
+        out, _, _ = ops.conv2d(a, *e["c2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip)
+        return out
+
+    def _attn(self, e, x, F_, H, W):
+        """Single-head attention over HW tokens with d = C (ae_modules.py:53-78) as batched MFMA GEMMs + fp32 row softmax."""
+        N, C_ = H * W, x.shape[1]
+        dt = x.dtype
+        Np = (N + ops.k_align(dt) - 1) // ops.k_align(dt) * ops.k_align(dt)
+        hn = ops.groupnorm(x, *e["norm"], F=F_, HW=N, eps=1e-6)
+        qk = ops.linear(hn, *e["qk"])                                             # [F*N, 2C]
+        scores = torch.empty((F_ * N, N), device=x.device, dtype=torch.float32)
+        ops.batched_gemm(qk[:, :C_], qk[:, C_:], scores, batch=F_, M=N, N=N, K=C_, a_bs=N * 2 * C_, b_bs=N * 2 * C_, o_bs=N * N,
+                         alpha=float(int(C_) ** -0.5))
+        probs = torch.zeros((F_ * N, Np), device=x.device, dtype=dt) if Np != N else torch.empty((F_ * N, N), device=x.device, dtype=dt)
+        ops._lib.check(ops._lib.load().geo4d_softmax_rows(scores.data_ptr(), N, probs.data_ptr(), Np, F_ * N, N, 1.0,
+                                                           ops.dt_code(dt), ops._stream()), "geo4d_softmax_rows")
+        wv, bv = e["v"]
+        vt = torch.zeros((F_ * C_, Np), device=x.device, dtype=dt) if Np != N else torch.empty((F_ * C_, N), device=x.device, dtype=dt)
+        ops.batched_gemm(wv, hn, vt, batch=F_, M=C_, N=N, K=C_, a_bs=0, b_bs=N * C_, o_bs=C_ * Np, bias=bv, bias_per_row=True)
+        o = torch.empty((F_ * N, C_), device=x.device, dtype=dt)
+        ops.batched_gemm(probs, vt, o, batch=F_, M=N, N=C_, K=Np, a_bs=N * Np, b_bs=C_ * Np, o_bs=N * C_)
+        return ops.linear(o, *e["o"], residual=x)
+
+    def decoder_features(self, z):
+        """z [n, 4, h, w] (already divided by scale_factor) -> feature tokens [n*H*W, feat_ch], H, W (pre norm_out)."""
+        P = self._packed or self._pack()
+        n, zc, H, W = z.shape
+        dt = self.compute_dtype
+        x = ops.tokens_from_ncthw(z.float().reshape(n, zc, 1, H, W).contiguous(), None, P["cpad"], dt)
+        x = ops.linear(x, *P["pq"])
+        x, _, _ = ops.conv2d(x, *P["conv_in"], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1)
+        for kind, p, ci, co in self.plan:
+            if kind == "res":
+                x = self._resnet(P[p], x, n, H, W)
+            elif kind == "attn":
+                x = self._attn(P[p], x, n, H, W)
+            else:
+                x, H, W = ops.conv2d(x, *P[p], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2)
+        return x, H, W
+
+    def _head(self, head, feat, F_, H, W, out, T, nchw_channels):
+        gn, w, b = head
+        a = ops.groupnorm(feat, *gn, F=F_, HW=H * W, eps=1e-6, silu=True)
+        ops.conv2d(a, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, T=T, out=out, out_nchw=True, nchw_channels=nchw_channels)
+
+    def _conf(self, P, feat, F_, H, W):
+        h = feat
+        for e in P["adaptor"]:
+            h = self._resnet(e, h, F_, H, W)
+        return h
+
+    # ---- reference call surface ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, z, **kwargs):
+        n = z.shape[0]
+        feat, H, W = self.decoder_features(z)
+        P = self._packed
+        out = torch.empty((n, self.ddconfig["out_ch"], H, W), device=z.device, dtype=torch.float32)
+        self._head(P["head"], feat, n, H, W, out, 1, self.ddconfig["out_ch"])
+        return out
+
+    @torch.no_grad()
+    def decode_with_conf_adaptor(self, z, **kwargs):
+        if self.adaptorconfig is None:
+            raise RuntimeError("decode_with_conf_adaptor needs adaptorconfig")
+        n = z.shape[0]
+        feat, H, W = self.decoder_features(z)
+        P = self._packed
+        c_rgb, c_conf = self.ddconfig["out_ch"], self.adaptorconfig["out_ch"]
+        out = torch.empty((n, c_rgb + c_conf, H, W), device=z.device, dtype=torch.float32)
+        self._head(P["head"], feat, n, H, W, out, 1, c_rgb + c_conf)
+        self._head(P["adaptor_head"], self._conf(P, feat, n, H, W), n, H, W, out[:, c_rgb:], 1, c_rgb + c_conf)
+        return out
+
+    def encode(self, x, **kwargs):
+        raise NotImplementedError("VAE encode is SURVEY.md §8(f) N3 (conditioning front-end), not built in this round; "
+                                  "pass precomputed latents (c_concat)")
+
+    encode_with_adaptor = encode
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward is out of scope; use decode / decode_with_conf_adaptor")

@@ -37,6 +37,7 @@ typedef struct geo4d_conv_gemm_t {
     const float* rowbias;/* [M/rowbias_div][N] fp32 added per row group, may be NULL    */
     const void* R;       /* residual [M][ldr], dtype = out_dtype, may be NULL           */
     long lda, ldw, ldo, ldr;
+    long ldrb;           /* row pitch of rowbias in floats (0 = N)                      */
     long a_bs, w_bs, o_bs, r_bs; /* batch strides in elements (batched GEMM)            */
     int M, N, K, batch;
     int Cin;             /* channels per tap; multiple of 128 B worth of elements       */
@@ -47,7 +48,8 @@ typedef struct geo4d_conv_gemm_t {
     int act;             /* 0 none, 1 SiLU, 2 GEGLU (packed pairs of 32 columns)        */
     int dtype;           /* A/W element type                                            */
     int out_dtype;       /* O/R element type                                            */
-    int out_nchw;        /* 1: store O as [B][N][T][Hout*Wout]                          */
+    int out_nchw;        /* 1: store O as [B][ldo][T][Hout*Wout] (ldo = channel count of the
+                            destination tensor; O may point at a channel offset inside it) */
     int tile_hint;       /* 0 auto, 1..5 force a tile configuration (tests)             */
     float alpha;
 } geo4d_conv_gemm_t;
@@ -119,6 +121,9 @@ int geo4d_linear_small(const float* x, long ldx, const float* w, long ldw, const
 int geo4d_ddim_step(float* x, const float* v, const float* noise, float* pred_x0, const float* coef, const int* step_index,
                     long n, void* stream);
 int geo4d_advance_index(int* idx, int delta, void* stream);
+/* ts[b] = table[*idx] for b < B: the per-step `ts = torch.full((b,), step)` of ddim.py:170, read from a device table so
+ * the captured step graph is step-independent. */
+int geo4d_gather_timestep(const int* idx, const long* table, long* ts, int B, void* stream);
 
 const char* geo4d_last_error(void);
 int geo4d_abi_version(void);

@@ -1,0 +1,135 @@
+"""CPU tests of the host side: state_dict compatibility with the reference (names + shapes from fixtures produced by the
+reference classes), config registry, integer tables (bit-exact), window slicing, C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(G, name), weights_only=False)
+
+
+def _shapes(m):
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def test_unet_state_dict_matches_reference_tiny():
+    from geo4d_amd.unet import UNetModel
+    g = load("unet_tiny.pt")
+    assert _shapes(UNetModel(**g["unet_config"])) == g["shapes"]
+
+
+def test_unet_state_dict_matches_reference_full_config():
+    """The shipped yaml: 1516 tensors, 1438.9 M parameters, incl. `temopral_conv` and the Conv1d init_attn projections."""
+    from geo4d_amd.registry import load_config
+    from geo4d_amd.unet import UNetModel
+    g = load("unet_full.pt")
+    cfg = load_config(os.path.join(ROOT, "configs", "inference_geo4d.yaml"))
+    with torch.device("meta"):
+        m = UNetModel(**cfg.model.params.unet_config.params)
+    s = _shapes(m)
+    assert s == g["shapes"] and len(s) == 1516
+    assert sum(int(np.prod(v)) for v in s.values()) == 1438924112
+    assert s["input_blocks.1.0.temopral_conv.conv1.2.weight"] == (320, 320, 3, 1, 1)
+    assert s["init_attn.0.proj_in.weight"] == (512, 320, 1)
+    assert s["input_blocks.1.1.transformer_blocks.0.attn2.to_k_ip.weight"] == (320, 1024)
+
+
+def test_vae_state_dict_matches_reference():
+    from geo4d_amd.registry import load_config
+    from geo4d_amd.vae import AutoencoderKL
+    g = load("vae_tiny.pt")
+    assert _shapes(AutoencoderKL(ddconfig=g["ddconfig"], lossconfig={"target": "torch.nn.Identity"}, embed_dim=4,
+                                 adaptorconfig=g["adaptorconfig"])) == g["shapes"]
+    cfg = load_config(os.path.join(ROOT, "configs", "inference_geo4d.yaml"))
+    with torch.device("meta"):
+        m = AutoencoderKL(**cfg.pointmap_vae_config.params)
+    assert _shapes(m) == load("unet_full.pt")["vae_shapes"]
+
+
+def test_registry_builds_the_engine_from_yaml():
+    from geo4d_amd.registry import instantiate_from_config, load_config
+    cfg = load_config(os.path.join(ROOT, "configs", "inference_geo4d.yaml"))
+    model_cfg = cfg.pop("model")
+    model_cfg["params"]["unet_config"]["params"]["use_checkpoint"] = False   # as test_geo4d.py:321-322
+    with torch.device("meta"):
+        model = instantiate_from_config(model_cfg)
+        pvae = instantiate_from_config(cfg.pop("pointmap_vae_config"))
+    assert type(model).__name__ == "LatentVisualDiffusion" and model.model.diffusion_model.out_channels == 16
+    assert model.parameterization == "v" and model.scale_factor == 0.18215 and model.perframe_ae and model.use_dynamic_rescale
+    assert type(pvae).__name__ == "AutoencoderKL" and cfg.postprocess.n_iter == 500
+    with pytest.raises(KeyError):
+        instantiate_from_config({"params": {}})
+    assert instantiate_from_config("__is_unconditional__") is None
+
+
+def test_schedule_buffers_and_ddim_tables_match_reference():
+    from geo4d_amd.ddim import DDIMSampler, make_ddim_timesteps
+    from geo4d_amd.diffusion import LatentDiffusion
+    g = load("schedule.pt")
+    u = load("unet_tiny.pt")["unet_config"]
+    m = LatentDiffusion(unet_config={"target": "geo4d_amd.unet.UNetModel", "params": u}, parameterization="v",
+                        conditioning_key="hybrid", rescale_betas_zero_snr=True, linear_start=0.00085, linear_end=0.012,
+                        use_dynamic_rescale=True, base_scale=0.7, scale_factor=0.18215)
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "scale_arr"):
+        assert torch.equal(getattr(m, k), g[k]), k
+    for S in (5, 50):
+        assert np.array_equal(make_ddim_timesteps("uniform_trailing", S, 1000), g[f"ddim_timesteps_{S}"].numpy())
+        s = DDIMSampler(m)
+        s.make_schedule(S, "uniform_trailing", 0.0, verbose=False)
+        assert np.array_equal(s.ddim_alphas_prev, g[f"ddim_alphas_prev_{S}"].numpy())
+        assert torch.equal(s.ddim_scale_arr, g[f"ddim_scale_arr_{S}"]) and torch.equal(s.ddim_scale_arr_prev, g[f"ddim_scale_arr_prev_{S}"])
+        assert s.coef.shape == (S, 6) and torch.equal(s.ts_table.cpu(), g[f"ddim_timesteps_{S}"])
+        assert torch.all(s.coef[:, 5] == 0)
+
+
+def test_window_slices_bit_exact():
+    from geo4d_amd.pipeline import window_slices
+    for (T, stride), ref in load("glue.pt")["windows"].items():
+        assert [(s.start, s.stop) for s in window_slices(T, stride)] == ref
+        assert all(s.step == 1 for s in window_slices(T, stride))
+
+
+def test_postprocess_matches_reference_cpu():
+    from geo4d_amd.pipeline import postprocess_window
+    g = load("glue.pt")["post"]
+    o = postprocess_window(g["batch_samples"])
+    assert torch.equal(o["valid"], g["pnt_valid_mask"])
+    for k in ("pts3d", "conf", "inverse_depthmap"):
+        assert torch.allclose(o[k], g[k], rtol=1e-6, atol=1e-7), k
+
+
+def test_compute_path_refuses_cpu():
+    """No silent fallback: a CPU tensor / CPU module must raise, not run somewhere else."""
+    from geo4d_amd import _lib, ops
+    from geo4d_amd.unet import UNetModel
+    with pytest.raises(_lib.Geo4DNativeError):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+    m = UNetModel(**load("unet_tiny.pt")["unet_config"])
+    with pytest.raises(_lib.Geo4DNativeError):
+        m(torch.zeros(1, 20, 2, 8, 8), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 77 + 32, 128))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/geo4d_hip.h <-> libgeo4d_hip.so <-> ctypes table (no kernel is launched)."""
+    from geo4d_amd import _lib
+    with open(os.path.join(ROOT, "include", "geo4d_hip.h")) as f:
+        hdr = f.read()
+    declared = set(re.findall(r"\b(geo4d_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.geo4d_abi_version() == 1
+    assert ctypes.sizeof(_lib.ConvGemm) == 6 * 8 + 9 * 8 + 25 * 4 + 4, ctypes.sizeof(_lib.ConvGemm)
+    assert lib.geo4d_groupnorm_workspace(16, 2560, 32, 1) == (16 * 64 * 32 * 3 + 16 * 32 * 2) * 4
+    # argument validation happens on the host before any launch: bad descriptors return -EINVAL with a message
+    p = _lib.ConvGemm()
+    assert lib.geo4d_conv_gemm(ctypes.byref(p), None) == -22 and b"conv_gemm" in lib.geo4d_last_error()
