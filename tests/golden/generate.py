@@ -67,7 +67,7 @@ def ad(x):
     return x
 
 
-def tiny_configs(mc=64, ctx=128, vae_ch=32):
+def tiny_configs(mc=64, ctx=128, vae_ch=64):
     dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=vae_ch, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
     adp = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=1, ch=vae_ch, ch_mult=[1],

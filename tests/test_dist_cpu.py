@@ -1,0 +1,48 @@
+"""world_size-2 gloo test of the window sharding + all-gather reassembly (the N>1 path of bench.py / pipeline)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, num_windows, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from geo4d_amd import dist as gd
+    r, w, _ = gd.init_from_env(backend="gloo")
+    mine = gd.shard_windows(num_windows, r, w)
+    local = torch.stack([torch.full((3, 4), float(i)) for i in mine]) if mine else torch.zeros((0, 3, 4))
+    full = gd.all_gather_windows(local, num_windows)
+    ok = all(bool((full[i] == float(i)).all()) for i in range(num_windows)) and full.shape == (num_windows, 3, 4)
+    q.put((rank, mine, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_sharding_and_allgather_world2():
+    ctx = mp.get_context("spawn")
+    for num_windows in (5, 14):          # odd count: rank 1 holds one window fewer (padded chunk)
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, num_windows, q)) for r in range(2)]
+        [p.start() for p in procs]
+        res = sorted(q.get(timeout=120) for _ in range(2))
+        [p.join(timeout=60) for p in procs]
+        assert res[0][1] == list(range(0, num_windows, 2)) and res[1][1] == list(range(1, num_windows, 2))
+        assert res[0][2] and res[1][2]
+
+
+def test_shard_tables():
+    from geo4d_amd.dist import shard_windows, window_owner_table
+    assert [len(shard_windows(30, r, 8)) for r in range(8)] == [4, 4, 4, 4, 4, 4, 3, 3]
+    assert window_owner_table(14, 8) == ([2, 2, 2, 2, 2, 2, 1, 1], 2)
+    assert sorted(sum((shard_windows(14, r, 8) for r in range(8)), [])) == list(range(14))
