@@ -6,6 +6,10 @@ import of any compute path raises immediately (``Geo4DNativeError``) instead of 
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its own libamdhip64.so; loading ours first would
+#                              bind it to /opt/rocm's copy and the process would hold two HIP runtimes (streams from one
+#                              are invalid in the other: "no ROCm-capable device is detected" at the first launch).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
 ABI_VERSION = 1

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Per-shape throughput of geo4d_conv_gemm on the GEMM / conv census of one U-Net forward at config A
+ and of the VAE decoder. HIP-event timing on the launch stream, random bf16 data.
+
+usage (GPU box): python tools/gemm_bench.py [--dtype bf16] [--iters 20] [--filter conv]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from geo4d_amd import ops  # noqa: E402
+
+# (name, kind, M-geometry, N, Cin, count per U-Net forward)
+# kind: lin (K=Cin) | c3 (3x3 conv, K=9*Cin, geometry F,H,W) | t3 (temporal 3-tap, K=3*Cin) | geglu
+SHAPES = [
+    ("L0 conv3x3 320->320", "c3", (16, 40, 64), 320, 320, 7),
+    ("L0 conv3x3 640->320", "c3", (16, 40, 64), 320, 640, 2),
+    ("L0 conv3x3 960->320", "c3", (16, 40, 64), 320, 960, 1),
+    ("L1 conv3x3 640->640", "c3", (16, 20, 32), 640, 640, 6),
+    ("L1 conv3x3 1920->640", "c3", (16, 20, 32), 640, 1920, 1),
+    ("L2 conv3x3 1280->1280", "c3", (16, 10, 16), 1280, 1280, 7),
+    ("L2 conv3x3 2560->1280", "c3", (16, 10, 16), 1280, 2560, 2),
+    ("L3 conv3x3 1280->1280", "c3", (16, 5, 8), 1280, 1280, 11),
+    ("L3 conv3x3 2560->1280", "c3", (16, 5, 8), 1280, 2560, 3),
+    ("L0 conv3d 320", "t3", (16, 2560), 320, 320, 20),
+    ("L1 conv3d 640", "t3", (16, 640), 640, 640, 20),
+    ("L2 conv3d 1280", "t3", (16, 160), 1280, 1280, 20),
+    ("L3 conv3d 1280", "t3", (16, 40), 1280, 1280, 28),
+    ("L0 qkv 320->960", "lin", 40960, 960, 320, 15),
+    ("L0 proj 320->320", "lin", 40960, 320, 320, 45),
+    ("L0 geglu 320->2560", "geglu", 40960, 2560, 320, 10),
+    ("L0 ffout 1280->320", "lin", 40960, 320, 1280, 10),
+    ("L1 qkv 640->1920", "lin", 10240, 1920, 640, 15),
+    ("L1 proj 640->640", "lin", 10240, 640, 640, 45),
+    ("L1 geglu 640->5120", "geglu", 10240, 5120, 640, 10),
+    ("L1 ffout 2560->640", "lin", 10240, 640, 2560, 10),
+    ("L2 qkv 1280->3840", "lin", 2560, 3840, 1280, 15),
+    ("L2 proj 1280->1280", "lin", 2560, 1280, 1280, 45),
+    ("L2 geglu 1280->10240", "geglu", 2560, 10240, 1280, 10),
+    ("L2 ffout 5120->1280", "lin", 2560, 1280, 5120, 10),
+    ("VAE conv3x3 512 @40x64 x48f", "c3", (48, 40, 64), 512, 512, 0),
+    ("VAE conv3x3 512 @80x128 x48f", "c3", (48, 80, 128), 512, 512, 0),
+    ("VAE conv3x3 256 @160x256 x48f", "c3", (48, 160, 256), 256, 256, 0),
+    ("VAE conv3x3 128 @320x512 x16f", "c3", (16, 320, 512), 128, 128, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--filter", default="")
+    ap.add_argument("--tile", type=int, default=0)
+    args = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    dev = torch.device("cuda:0")
+    tot_ms, tot_tf = 0.0, 0.0
+    print(f"{'shape':34s} {'M':>8s} {'N':>6s} {'K':>6s} {'us':>9s} {'TF/s':>8s}  x count -> ms/forward")
+    for name, kind, geo, N, Cin, cnt in SHAPES:
+        if args.filter and args.filter not in name:
+            continue
+        if kind == "c3":
+            F_, H, W = geo
+            M, K = F_ * H * W, 9 * Cin
+            x = torch.randn((M, Cin), device=dev).to(dt)
+            w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
+            b = torch.randn((N,), device=dev)
+            r = torch.randn((M, N), device=dev).to(dt)
+            fn = lambda: ops.conv2d(x, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=r, tile_hint=args.tile)
+        elif kind == "t3":
+            T, HW = geo
+            M, K = T * HW, 3 * Cin
+            x = torch.randn((M, Cin), device=dev).to(dt)
+            w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
+            b = torch.randn((N,), device=dev)
+            fn = lambda: ops.conv_temporal(x, w, b, B=1, T=T, HW=HW, residual=x)
+        else:
+            M, K = geo, Cin
+            x = torch.randn((M, K), device=dev).to(dt)
+            w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
+            b = torch.randn((N,), device=dev)
+            act = 2 if kind == "geglu" else 0
+            fn = lambda: ops.linear(x, w, b, act=act, tile_hint=args.tile)
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        tf = 2.0 * M * N * K / us / 1e6
+        tot_ms += us * cnt / 1e3
+        tot_tf += 2.0 * M * N * K * cnt / 1e12
+        print(f"{name:34s} {M:8d} {N:6d} {K:6d} {us:9.1f} {tf:8.1f}  x{cnt:3d} -> {us * cnt / 1e3:7.2f}")
+    if tot_ms:
+        print(f"U-Net GEMM census: {tot_tf:.2f} TFLOP in {tot_ms:.1f} ms = {tot_tf / tot_ms * 1e3:.0f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
