@@ -25,6 +25,7 @@ class ConvGemm(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("W", C.c_void_p), ("O", C.c_void_p),
         ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("R", C.c_void_p),
+        ("zeros", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("lda", C.c_long), ("ldw", C.c_long), ("ldo", C.c_long), ("ldr", C.c_long), ("ldrb", C.c_long),
         ("a_bs", C.c_long), ("w_bs", C.c_long), ("o_bs", C.c_long), ("r_bs", C.c_long),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
@@ -34,7 +35,7 @@ class ConvGemm(C.Structure):
         ("stride", C.c_int), ("ups", C.c_int),
         ("rowbias_div", C.c_int), ("bias_per_row", C.c_int), ("act", C.c_int),
         ("dtype", C.c_int), ("out_dtype", C.c_int), ("out_nchw", C.c_int), ("tile_hint", C.c_int),
-        ("alpha", C.c_float),
+        ("split_k", C.c_int), ("alpha", C.c_float),
     ]
 
 

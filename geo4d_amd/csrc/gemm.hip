@@ -10,19 +10,32 @@
 // Activations are channels-last tokens [F, H*W, C]; weights are packed [N][taps*Cin] (K-major, tap-major).
 // out[m][n] = epilogue(alpha * sum_k A_gather[m][k] * W[n][k])
 //
-// Tile: BM x BN x 128 bytes of K per stage, 256 threads = 4 waves, each wave owns (BM/WM) x (BN/WN) as
-// 32x32 MFMA blocks. Register-staged global->LDS with a 2-deep LDS ring (one barrier per stage), LDS rows
-// padded to 144 B so that both the ds_write_b128 (8 lanes = one row) and the fragment ds_read_b128
-// (16-lane groups, 16 distinct rows) are bank-conflict free (MI355X_MICROARCH.md §LDS).
-// Workgroup ids are remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles with the
-// N-tile index fastest: neighbours share the gathered A panel.
+// Structure (256 threads = 4 waves, tile BM x BN x 128 B of K per stage):
+//   * gather table: the source pixel of every (tile row, tap) is resolved ONCE per workgroup into LDS
+//     (-1 = zero padding), so the K loop does one ds_read + one 64-bit mad per 16-byte chunk instead of
+//     re-deriving (frame, y, x), bounds and upsample/stride arithmetic every stage;
+//   * global->LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip and no
+//     ds_write: the ds_write_b128 path tops out at ~79 B/clk/CU and was the limiter of the register-staged version),
+//     2-deep LDS ring, one vmcnt(0)+barrier per stage. The DMA image is lane-linear (8 lanes = one 128-byte row),
+//     so bank conflicts are removed by an XOR swizzle applied on the SOURCE address (slot = chunk ^ ((row>>1)&7))
+//     and mirrored on the fragment ds_read_b128 (conflict-free for all four 16-lane service groups);
+//     zero padding = lanes whose tap falls outside the image fetch from a 16-byte zero block;
+//   * swapped MFMA operands: the weight fragment is the MFMA "A" side, the activation fragment the "B" side,
+//     so a lane owns ONE output row m and 4 consecutive output columns n per register quad;
+//   * epilogue through LDS (fp32): bias / row-bias / SiLU / GEGLU applied in registers, tile transposed
+//     through the (now idle) stage buffers, then residual add + rounding + fully coalesced 16-byte stores;
+//   * optional split-K (gridDim.z) into fp32 partial slabs + a deterministic fixed-order reduce kernel
+//     carrying the epilogue — for the 5x8 / 10x16 levels whose M x N tile count cannot fill 256 CUs;
+//   * workgroup ids remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles with the
+//     N-tile index fastest: neighbours share the gathered A panel.
 #include "common.h"
 #include "geo4d_hip.h"
 
 namespace {
 
-constexpr int PITCH = 144;  // LDS row pitch in bytes (128 B payload + 16 B pad)
+constexpr int PITCH = 128;  // LDS row pitch in bytes: 8 x 16-byte slots, XOR-swizzled
 constexpr int BKC = 8;      // 16-byte chunks per row per stage
+constexpr int MAXTAP = 9;
 
 __device__ __forceinline__ void store_out(void* O, long idx, float v, int dt) {
     if (dt == GEO4D_F32) ((float*)O)[idx] = v;
@@ -35,15 +48,29 @@ __device__ __forceinline__ float load_res(const void* R, long idx, int dt) {
     return f16_bits_to_f32(((const unsigned short*)R)[idx]);
 }
 
+template <int BM, int BN, int WM, int WN>
+constexpr int stage_bytes() {
+    constexpr int ring = 2 * (BM + BN) * PITCH;
+    constexpr int epi = 4 * (BM / WM) * (BN / WN + 4) * 4;   // fp32 transpose tiles of the 4 waves
+    return ring > epi ? ring : epi;
+}
+template <int BM, int BN, int WM, int WN>
+constexpr int smem_bytes() {
+    return stage_bytes<BM, BN, WM, WN>() + BM * MAXTAP * 4;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = BKC * EPC;
     constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
     constexpr int ACH = BM * BKC / 256, BCH = BN * BKC / 256;
+    constexpr int WTM = MB * 32, WTN = NB * 32;   // wave tile
+    constexpr int SP = WTN + 4;                   // fp32 staging pitch (floats)
     static_assert(WM * WN == 4, "4 waves");
     static_assert(MB >= 1 && NB >= 1 && ACH >= 1 && BCH >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* rowpix = (int*)(smem + stage_bytes<BM, BN, WM, WN>());
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
@@ -52,79 +79,86 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tm = (int)(lid / tiles_n), tn = (int)(lid - (long)tm * tiles_n);
     const long bz = blockIdx.y;
+    const int kz = blockIdx.z;
     const T* __restrict__ A = (const T*)p.A + bz * p.a_bs;
     const T* __restrict__ W = (const T*)p.W + bz * p.w_bs;
+    const int ntap = p.KT * p.KH * p.KW;
+    const int hw = p.Hout * p.Wout;
+
+    // ---- gather table: source pixel index of (tile row, tap), -1 where the tap falls into padding ------
+    {
+        const int hlim = p.ups == 2 ? 2 * p.Hin : p.Hin, wlim = p.ups == 2 ? 2 * p.Win : p.Win;
+        const int ush = p.ups == 2 ? 1 : 0;
+        for (int e = tid; e < BM * ntap; e += 256) {
+            const int row = e / ntap, tap = e - row * ntap;
+            const int m = tm * BM + row;
+            int pix = -1;
+            if (m < p.M) {
+                const int f = m / hw, rem = m - f * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                const int kt = tap / (p.KH * p.KW), r2 = tap - kt * (p.KH * p.KW);
+                const int ky = r2 / p.KW, kx = r2 - ky * p.KW;
+                const int iy = oy * p.stride - p.ph + ky, ix = ox * p.stride - p.pw + kx;
+                const int tt = (f % p.T) + kt - p.pt;
+                if ((unsigned)iy < (unsigned)hlim && (unsigned)ix < (unsigned)wlim && (unsigned)tt < (unsigned)p.T)
+                    pix = ((f + kt - p.pt) * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
+            }
+            rowpix[e] = pix;
+        }
+    }
+    __syncthreads();
 
     const int ccol = tid & 7;
     const int r0 = tid >> 3;
-
-    // ---- decode the output pixels of the A rows this thread stages ------------------------
-    int rf[ACH], rt[ACH], ry[ACH], rx[ACH];
-    bool rv[ACH];
-    const int hw = p.Hout * p.Wout;
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-        const int m = tm * BM + r0 + i * 32;
-        rv[i] = m < p.M;
-        const int mm = rv[i] ? m : 0;
-        const int f = mm / hw;
-        const int rem = mm - f * hw;
-        const int oy = rem / p.Wout;
-        const int ox = rem - oy * p.Wout;
-        rf[i] = f;
-        rt[i] = f % p.T;
-        ry[i] = oy * p.stride - p.ph;
-        rx[i] = ox * p.stride - p.pw;
-    }
-    long wrow[BCH];
-    bool wv[BCH];
+    // source-side swizzle: LDS slot `ccol` of row r holds global chunk ccol ^ ((r >> 1) & 7); rows advance by 32 per
+    // staging pass, so the XOR term is a per-thread constant
+    const int csrc = (ccol ^ ((r0 >> 1) & 7)) * EPC;
+    const T* __restrict__ Z = (const T*)p.zeros;
+    const T* wptr[BCH];
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
         const int n = tn * BN + r0 + i * 32;
-        wv[i] = n < p.N;
-        wrow[i] = (long)(wv[i] ? n : 0) * p.ldw + ccol * EPC;
+        wptr[i] = n < p.N ? W + (long)n * p.ldw + csrc : nullptr;
     }
-    const int hlim = p.ups == 2 ? 2 * p.Hin : p.Hin;
-    const int wlim = p.ups == 2 ? 2 * p.Win : p.Win;
-    const int ush = p.ups == 2 ? 1 : 0;
 
-    u32x4 ra[ACH], rb[BCH];
-    // slab cursor (uniform across the block)
-    int c0 = 0, kx = 0, ky = 0, kt = 0;
-    long k0 = 0;
-    auto load_slab = [&]() {
+    // K range of this workgroup (split-K over gridDim.z)
+    const int nslab_all = p.K / BK;
+    const int per = (nslab_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int s_begin = kz * per;
+    const int s_end = min(nslab_all, s_begin + per);
+    const int nslab = s_end - s_begin;
+
+    int pix[ACH];
+    const int slabs_per_tap = p.Cin / BK;
+    int tap = s_begin / slabs_per_tap;
+    int c0 = (s_begin - tap * slabs_per_tap) * BK;
+    long k0 = (long)s_begin * BK;
+    auto fetch_pix = [&]() {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) pix[i] = rowpix[(r0 + i * 32) * ntap + tap];
+    };
+    // one LDS-DMA per 8 rows: wave-uniform destination (M0) + lane * 16 B
+    auto issue_slab = [&](int buf) {
+        char* base = smem + buf * (BM + BN) * PITCH + wave * 1024;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            const int iy = ry[i] + ky, ix = rx[i] + kx, tt = rt[i] + kt - p.pt;
-            const bool ok = rv[i] && (unsigned)iy < (unsigned)hlim && (unsigned)ix < (unsigned)wlim &&
-                            (unsigned)tt < (unsigned)p.T;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const long pix = ((long)(rf[i] + kt - p.pt) * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
-                v = *(const u32x4*)(A + pix * p.lda + c0 + ccol * EPC);
-            }
-            ra[i] = v;
+            const T* src = pix[i] >= 0 ? A + (long)pix[i] * p.lda + c0 + csrc : Z;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + i * 32 * PITCH), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (wv[i]) v = *(const u32x4*)(W + wrow[i] + k0);
-            rb[i] = v;
+            const T* src = wptr[i] ? wptr[i] + k0 : Z;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + (BM + i * 32) * PITCH), 16, 0, 0);
         }
-        // advance cursor
         k0 += BK;
         c0 += BK;
         if (c0 >= p.Cin) {
             c0 = 0;
-            if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; ++kt; } }
+            ++tap;
+            if (tap < ntap) fetch_pix();
         }
-    };
-    auto store_slab = [&](int buf) {
-        char* base = smem + buf * (BM + BN) * PITCH;
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) *(u32x4*)(base + (r0 + i * 32) * PITCH + ccol * 16) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) *(u32x4*)(base + (BM + r0 + i * 32) * PITCH + ccol * 16) = rb[i];
     };
 
     f32x16 acc[MB][NB];
@@ -135,104 +169,229 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nslab = p.K / BK;
-    load_slab();
-    store_slab(0);
-    __syncthreads();
+    // fragment read offsets: logical chunk (2kk + g) of row li lives in slot (2kk + g) ^ ((li >> 1) & 7)
+    int foff[BKC / 2];
+#pragma unroll
+    for (int kk = 0; kk < BKC / 2; ++kk) foff[kk] = li * PITCH + (((2 * kk + g) ^ ((li >> 1) & 7)) << 4);
+
+    if (nslab > 0) {
+        fetch_pix();
+        issue_slab(0);
+    }
+    __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nslab) load_slab();
-        const char* abase = smem + buf * (BM + BN) * PITCH + (wr * MB * 32 + li) * PITCH + g * 16;
-        const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * NB * 32 + li) * PITCH + g * 16;
+        if (s + 1 < nslab) issue_slab(buf ^ 1);
+        const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
+        const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
 #pragma unroll
         for (int kk = 0; kk < BKC / 2; ++kk) {
             u32x4 fa[MB], fb[NB];
 #pragma unroll
-            for (int a = 0; a < MB; ++a) fa[a] = *(const u32x4*)(abase + a * 32 * PITCH + kk * 32);
+            for (int a = 0; a < MB; ++a) fa[a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[kk]);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) fb[b] = *(const u32x4*)(bbase + b * 32 * PITCH + kk * 32);
+            for (int b = 0; b < NB; ++b) fb[b] = *(const u32x4*)(bbase + b * 32 * PITCH + foff[kk]);
 #pragma unroll
             for (int a = 0; a < MB; ++a)
 #pragma unroll
-                for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fa[a], fb[b]);
+                for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fb[b], fa[a]);   // C rows = n, C cols = m
         }
-        if (s + 1 < nslab) store_slab(buf ^ 1);
-        __syncthreads();
+        __syncthreads();   // next stage landed (vmcnt(0)) and every wave is done reading this one
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
-    void* O = (char*)p.O;
-    const long obase = bz * p.o_bs;
-    const long rbase = bz * p.r_bs;
-    const int row_w0 = tm * BM + wr * MB * 32;
-    const int col_w0 = tn * BN + wc * NB * 32;
-    if (p.act == 2) {
-        if constexpr (NB == 2) {
-            // GEGLU: packed weights interleave 32 value columns with their 32 gate columns.
-            const int ocol = (col_w0 >> 1) + li;
-            const int ncol = p.N >> 1;
-            const float bx = p.bias ? p.bias[col_w0 + li] : 0.f;
-            const float bg = p.bias ? p.bias[col_w0 + 32 + li] : 0.f;
-            if (col_w0 + 32 + li < p.N) {
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // acc[a][b][r]: m = m_w0 + a*32 + li ; n = n_w0 + b*32 + 8*(r>>2) + 4*g + (r&3)
+    const int m_w0 = tm * BM + wr * WTM;
+    const int n_w0 = tn * BN + wc * WTN;
+    const bool partial = gridDim.z > 1;          // split-K: raw fp32 slab, epilogue runs in the reduce kernel
+    const int odt = partial ? GEO4D_F32 : p.out_dtype;
+    void* O = partial ? (void*)((float*)p.workspace + ((long)kz * p.batch + bz) * (long)p.M * p.N) : p.O;
+    const long ldo = partial ? (long)p.N : p.ldo;
+    const long obase = partial ? 0 : bz * p.o_bs;
+    const bool geglu = !partial && p.act == 2;
+    const int oesz = odt == GEO4D_F32 ? 4 : 2;
+    const int nout = geglu ? (p.N >> 1) : p.N;
+    const bool vec_ok = !p.out_nchw && ((ldo * oesz) & 15) == 0 && (nout & 7) == 0 && (((uintptr_t)O + obase * oesz) & 15) == 0 &&
+                        (partial || !p.R || (((p.ldr * oesz) & 15) == 0 && (((uintptr_t)p.R + bz * p.r_bs * oesz) & 15) == 0));
+
+    if (!vec_ok) {
+        // direct path (NCTHW heads with N = 16 / 3 / 1, odd shapes): lanes run along m -> coalesced along pixels
 #pragma unroll
-                for (int a = 0; a < MB; ++a)
+        for (int a = 0; a < MB; ++a) {
+            const int m = m_w0 + a * 32 + li;
+            if (m >= p.M) continue;
+            long orow, ocol;
+            if (p.out_nchw && !partial) {
+                const int f = m / hw;
+                const int bb = f / p.T, tt = f - bb * p.T;
+                orow = ((long)bb * p.ldo * p.T + tt) * hw + (m - f * hw);   // ldo = channels of the NCTHW tensor
+                ocol = (long)p.T * hw;
+            } else {
+                orow = (long)m * ldo;
+                ocol = 1;
+            }
+            const float brow = (!partial && p.bias && p.bias_per_row) ? p.bias[m] : 0.f;
+            const long rboff = (!partial && p.rowbias) ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
+            if (geglu) {
+                if constexpr (NB == 2) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = row_w0 + a * 32 + acc_row(r, g);
-                        if (row < p.M) {
-                            const float xv = acc[a][0][r] * p.alpha + bx;
-                            const float gv = acc[a][1][r] * p.alpha + bg;
-                            store_out(O, obase + (long)row * p.ldo + ocol, xv * gelu_erf_f(gv), p.out_dtype);
-                        }
+                        const int nn = n_w0 + 8 * (r >> 2) + 4 * g + (r & 3);
+                        if (nn + 32 >= p.N) continue;
+                        const float xv = acc[a][0][r] * p.alpha + (p.bias ? p.bias[nn] : 0.f);
+                        const float gv = acc[a][1][r] * p.alpha + (p.bias ? p.bias[nn + 32] : 0.f);
+                        store_out(O, obase + orow + (long)((n_w0 >> 1) + 8 * (r >> 2) + 4 * g + (r & 3)) * ocol, xv * gelu_erf_f(gv), odt);
                     }
+                }
+                continue;
             }
-            (void)ncol;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n_w0 + b * 32 + 8 * (r >> 2) + 4 * g + (r & 3);
+                    if (n >= p.N) continue;
+                    float v = acc[a][b][r];
+                    if (!partial) {
+                        v = v * p.alpha + brow;
+                        if (p.bias && !p.bias_per_row) v += p.bias[n];
+                        if (p.rowbias) v += p.rowbias[rboff + n];
+                        if (p.act == 1) v = silu_f(v);
+                        if (p.R) v += load_res(p.R, bz * p.r_bs + (long)m * p.ldr + n, odt);
+                    }
+                    store_out(O, obase + orow + (long)n * ocol, v, odt);
+                }
         }
         return;
     }
-    float bcol[NB];
-    bool cok[NB];
+
+    // staged path: registers -> fp32 LDS tile [m][n] per wave -> coalesced 16-byte rows
+    float* stg = (float*)smem + wave * (WTM * SP);
+    const int ncols_w = geglu ? WTN / 2 : WTN;             // staged columns per wave
+    const int ocol_w0 = geglu ? (n_w0 >> 1) : n_w0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int col = col_w0 + b * 32 + li;
-        cok[b] = col < p.N;
-        bcol[b] = (p.bias && !p.bias_per_row && cok[b]) ? p.bias[col] : 0.f;
-    }
+    for (int a = 0; a < MB; ++a) {
+        const int m = m_w0 + a * 32 + li;
+        const float brow = (!partial && p.bias && p.bias_per_row && m < p.M) ? p.bias[m] : 0.f;
+        const long rboff = (!partial && p.rowbias && m < p.M) ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
+        if (geglu) {
+            if constexpr (NB == 2) {
 #pragma unroll
-    for (int a = 0; a < MB; ++a)
+                for (int q = 0; q < 4; ++q) {
+                    const int nn = n_w0 + 8 * q + 4 * g;
+                    f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row_w0 + a * 32 + acc_row(r, g);
-            if (row >= p.M) continue;
-            const float brow = (p.bias && p.bias_per_row) ? p.bias[row] : 0.f;
-            const long rboff = p.rowbias ? (long)(row / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
-            long obase_row, ostride_col;
-            if (p.out_nchw) {
-                // [B][N][T][hw]  (T = 1 gives plain NCHW per frame)
-                const int f = row / hw;
-                const int bb = f / p.T, tt = f - bb * p.T;
-                obase_row = ((long)bb * p.ldo * p.T + tt) * hw + (row - f * hw);  // ldo = channels of the NCTHW tensor
-                ostride_col = (long)p.T * hw;
-            } else {
-                obase_row = (long)row * p.ldo;
-                ostride_col = 1;
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = nn + 32 + j < p.N;
+                        const float xv = acc[a][0][4 * q + j] * p.alpha + ((p.bias && ok) ? p.bias[nn + j] : 0.f);
+                        const float gv = acc[a][1][4 * q + j] * p.alpha + ((p.bias && ok) ? p.bias[nn + 32 + j] : 0.f);
+                        o[j] = xv * gelu_erf_f(gv);
+                    }
+                    *(f32x4*)(stg + (a * 32 + li) * SP + 8 * q + 4 * g) = o;
+                }
             }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (!cok[b]) continue;
-                const int col = col_w0 + b * 32 + li;
-                float v = acc[a][b][r] * p.alpha + bcol[b] + brow;
-                if (p.rowbias) v += p.rowbias[rboff + col];
-                if (p.act == 1) v = silu_f(v);
-                if (p.R) v += load_res(p.R, rbase + (long)row * p.ldr + col, p.out_dtype);
-                store_out(O, obase + obase_row + (long)col * ostride_col, v, p.out_dtype);
-            }
+            continue;
         }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_w0 + b * 32 + 8 * q + 4 * g;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[a][b][4 * q + j];
+                    if (!partial) {
+                        v = v * p.alpha + brow;
+                        if (n + j < p.N) {
+                            if (p.bias && !p.bias_per_row) v += p.bias[n + j];
+                            if (p.rowbias) v += p.rowbias[rboff + n + j];
+                        }
+                        if (p.act == 1) v = silu_f(v);
+                    }
+                    o[j] = v;
+                }
+                *(f32x4*)(stg + (a * 32 + li) * SP + b * 32 + 8 * q + 4 * g) = o;
+            }
+    }
+    __syncthreads();
+    // read back: 8 output elements per lane (two 16-byte LDS reads), rows of the wave tile in passes
+    const int cpr = ncols_w / 8;                 // 8-element chunks per staged row (8, 4 or 2)
+    const int rows_per_pass = 64 / cpr;
+    const int lc = lane % cpr, lr = lane / cpr;
+    for (int rr = lr; rr < WTM; rr += rows_per_pass) {
+        const int m = m_w0 + rr;
+        const int n = ocol_w0 + lc * 8;
+        if (m >= p.M || n >= nout) continue;
+        const f32x4 v0 = *(const f32x4*)(stg + rr * SP + lc * 8);
+        const f32x4 v1 = *(const f32x4*)(stg + rr * SP + lc * 8 + 4);
+        float e[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const long oidx = obase + (long)m * ldo + n;
+        if (odt == GEO4D_F32) {
+            if (!partial && p.R) {
+                const float* rp = (const float*)p.R + bz * p.r_bs + (long)m * p.ldr + n;
+                const f32x4 r0v = *(const f32x4*)rp, r1v = *(const f32x4*)(rp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { e[j] += r0v[j]; e[4 + j] += r1v[j]; }
+            }
+            f32x4 o0 = {e[0], e[1], e[2], e[3]}, o1 = {e[4], e[5], e[6], e[7]};
+            *(f32x4*)((float*)O + oidx) = o0;
+            *(f32x4*)((float*)O + oidx + 4) = o1;
+        } else if (odt == GEO4D_BF16) {
+            if (p.R) {
+                float r[8];
+                chunk_to_f32<bf16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)m * p.ldr + n), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] += r[j];
+            }
+            *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<bf16_t>(e);
+        } else {
+            if (p.R) {
+                float r[8];
+                chunk_to_f32<f16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)m * p.ldr + n), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] += r[j];
+            }
+            *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<f16_t>(e);
+        }
+    }
+}
+
+// out = epilogue(sum_z partial[z]) in fixed z order (deterministic); 8 consecutive n per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const geo4d_conv_gemm_t p, int splits) {
+    const long total = (long)p.batch * p.M * (p.N / 8);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)(i % (p.N / 8)) * 8;
+    const long bm = i / (p.N / 8);
+    const int m = (int)(bm % p.M);
+    const long bz = bm / p.M;
+    const long slab = (long)p.batch * p.M * p.N;
+    const float* src = (const float*)p.workspace + (bz * p.M + m) * (long)p.N + n;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    for (int z = 0; z < splits; ++z) {
+        const f32x4 a = *(const f32x4*)(src + z * slab), b = *(const f32x4*)(src + z * slab + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e[j] += a[j]; e[4 + j] += b[j]; }
+    }
+    const float brow = (p.bias && p.bias_per_row) ? p.bias[m] : 0.f;
+    const long rboff = p.rowbias ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = e[j] * p.alpha + brow;
+        if (p.bias && !p.bias_per_row) v += p.bias[n + j];
+        if (p.rowbias) v += p.rowbias[rboff + n + j];
+        if (p.act == 1) v = silu_f(v);
+        if (p.R) v += load_res(p.R, bz * p.r_bs + (long)m * p.ldr + n + j, p.out_dtype);
+        store_out(p.O, bz * p.o_bs + (long)m * p.ldo + n + j, v, p.out_dtype);
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg(const geo4d_conv_gemm_t& p, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * PITCH;
+int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
+    constexpr int smem = smem_bytes<BM, BN, WM, WN>();
     static bool attr_set = false;
     auto kern = conv_gemm_kernel<T, BM, BN, WM, WN>;
     if (!attr_set) {
@@ -243,20 +402,29 @@ int launch_cfg(const geo4d_conv_gemm_t& p, hipStream_t stream) {
         attr_set = true;
     }
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    dim3 grid((unsigned)tiles, (unsigned)p.batch, 1);
+    dim3 grid((unsigned)tiles, (unsigned)p.batch, (unsigned)splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
     GEO4D_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long total = (long)p.batch * p.M * (p.N / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);
+        GEO4D_CHECK_LAUNCH();
+    }
     return GEO4D_OK;
 }
 
 // Tile choice: score = MFMA efficiency of the tile shape x useful fraction x how full the last wave of
-// workgroups is (2 workgroups fit per CU by LDS => 512 slots on 256 CUs).
+// workgroups is (2 workgroups fit per CU by LDS => 512 slots on 256 CUs). Split-K multiplies the workgroup count
+// when M x N alone cannot fill the chip and K is deep enough to amortise the extra fp32 slab traffic.
 struct TileCfg { int bm, bn; float eff; };
 
 template <typename T>
 int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     static const TileCfg cfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.80f}, {64, 64, 0.62f}, {128, 32, 0.50f}};
-    int best = -1;
+    const int bk = BKC * Elem<T>::EPC;
+    const int nslab = p.K / bk;
+    const bool can_split = p.workspace && p.act != 2 && !p.out_nchw && (p.N % 8) == 0 && p.split_k != 1;
+    int best = -1, best_split = 1;
     float best_score = -1.f;
     for (int i = 0; i < 5; ++i) {
         const TileCfg& c = cfgs[i];
@@ -265,19 +433,26 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
         const double tm = (p.M + c.bm - 1) / c.bm, tn = (p.N + c.bn - 1) / c.bn;
         const double tiles = tm * tn * p.batch;
         const double useful = ((double)p.M * p.N * p.batch) / (tiles * c.bm * c.bn);
-        const double waves = (tiles + 511) / 512;
-        const double fill = tiles / (double)((long)waves * 512);
-        const float score = (float)(c.eff * useful * (0.35 + 0.65 * fill));
-        if (score > best_score) { best_score = score; best = i; }
+        for (int s = 1; s <= 16; s *= 2) {
+            if (s > 1 && (!can_split || nslab / s < 8)) break;
+            if (p.split_k > 1 && s != p.split_k) continue;
+            if (s > 1 && (size_t)s * p.batch * p.M * p.N * 4 > p.workspace_bytes) break;
+            const double wgs = tiles * s;
+            const double waves = (double)(long)((wgs + 511) / 512);
+            const double fill = wgs / (waves * 512);
+            const double split_cost = s > 1 ? 0.92 : 1.0;      // slab write + reduce kernel
+            const float score = (float)(c.eff * useful * (0.30 + 0.70 * fill) * split_cost);
+            if (score > best_score) { best_score = score; best = i; best_split = s; }
+        }
     }
     switch (best) {
-        case 0: return launch_cfg<T, 128, 128, 2, 2>(p, stream);
-        case 1: return launch_cfg<T, 128, 64, 4, 1>(p, stream);
-        case 2: return launch_cfg<T, 64, 128, 2, 2>(p, stream);
-        case 3: return launch_cfg<T, 64, 64, 2, 2>(p, stream);
-        case 4: return launch_cfg<T, 128, 32, 4, 1>(p, stream);
+        case 0: return launch_cfg<T, 128, 128, 2, 2>(p, best_split, stream);
+        case 1: return launch_cfg<T, 128, 64, 4, 1>(p, best_split, stream);
+        case 2: return launch_cfg<T, 64, 128, 2, 2>(p, best_split, stream);
+        case 3: return launch_cfg<T, 64, 64, 2, 2>(p, best_split, stream);
+        case 4: return launch_cfg<T, 128, 32, 4, 1>(p, best_split, stream);
     }
-    geo4d_set_error("conv_gemm: no tile configuration");
+    geo4d_set_error("conv_gemm: no tile configuration (split_k / tile_hint not applicable to this problem?)");
     return GEO4D_EINVAL;
 }
 
@@ -291,6 +466,7 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     const int bk = BKC * epc;
     if (p.dtype < 0 || p.dtype > 2 || p.out_dtype < 0 || p.out_dtype > 2) { geo4d_set_error("conv_gemm: bad dtype"); return GEO4D_EINVAL; }
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) { geo4d_set_error("conv_gemm: empty problem"); return GEO4D_EINVAL; }
+    if (p.KT <= 0 || p.KH <= 0 || p.KW <= 0 || p.KT * p.KH * p.KW > MAXTAP) { geo4d_set_error("conv_gemm: at most 9 taps"); return GEO4D_EINVAL; }
     if (p.Cin % bk || p.K != p.Cin * p.KT * p.KH * p.KW) { geo4d_set_error("conv_gemm: Cin must be a multiple of the 128-byte K slab and K = taps*Cin"); return GEO4D_EINVAL; }
     if ((p.lda * esz) % 16 || (p.ldw * esz) % 16 || ((uintptr_t)p.A % 16) || ((uintptr_t)p.W % 16) || (p.a_bs * esz) % 16 || (p.w_bs * esz) % 16) {
         geo4d_set_error("conv_gemm: operands must be 16-byte aligned");
@@ -298,10 +474,13 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     }
     if (p.T <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0 || p.M % (p.Hout * p.Wout)) { geo4d_set_error("conv_gemm: bad geometry"); return GEO4D_EINVAL; }
     if ((p.M / (p.Hout * p.Wout)) % p.T) { geo4d_set_error("conv_gemm: frames not a multiple of T"); return GEO4D_EINVAL; }
+    if ((long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win > 2147483647L) { geo4d_set_error("conv_gemm: more than 2^31 input pixels"); return GEO4D_EINVAL; }
     if (p.ups != 1 && p.ups != 2) { geo4d_set_error("conv_gemm: ups must be 1 or 2"); return GEO4D_EINVAL; }
     if (p.act == 2 && (p.N % 64 || p.out_nchw || p.R)) { geo4d_set_error("conv_gemm: GEGLU needs N % 64 == 0, row-major output, no residual"); return GEO4D_EINVAL; }
     if (p.rowbias && p.rowbias_div <= 0) { geo4d_set_error("conv_gemm: rowbias_div"); return GEO4D_EINVAL; }
     if (p.batch > 65535) { geo4d_set_error("conv_gemm: batch too large"); return GEO4D_EINVAL; }
+    if (!p.zeros || ((uintptr_t)p.zeros % 16)) { geo4d_set_error("conv_gemm: `zeros` must point at 16 zero bytes (16-byte aligned) in device memory"); return GEO4D_EINVAL; }
+    if (p.workspace && ((uintptr_t)p.workspace % 16)) { geo4d_set_error("conv_gemm: workspace alignment"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {
         case GEO4D_F32: return launch_typed<float>(p, s);

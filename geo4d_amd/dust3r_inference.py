@@ -1,0 +1,92 @@
+"""Call-surface shims for the names of ``dust3r/inference.py``.
+
+None of these are on the Geo4D inference path (the entry scripts never import ``dust3r.inference``); the north-star asks
+for the names to exist. They are plain-PyTorch host utilities with the reference signatures — no kernels, no hot path.
+"""
+import torch
+
+
+def _interleave(a, b):
+    out = {}
+    for k, va in a.items():
+        vb = b[k]
+        if isinstance(va, torch.Tensor) and va.ndim == vb.ndim:
+            out[k] = torch.stack((va, vb), dim=1).flatten(0, 1)
+        else:
+            out[k] = [x for pair in zip(va, vb) for x in pair]
+    return out
+
+
+def make_batch_symmetric(batch):
+    """dust3r/inference.py:27-30."""
+    v1, v2 = batch
+    return _interleave(v1, v2), _interleave(v2, v1)
+
+
+def check_if_same_size(pairs):
+    """dust3r/inference.py:104-107."""
+    s1 = [a["img"].shape[-2:] for a, _ in pairs]
+    s2 = [b["img"].shape[-2:] for _, b in pairs]
+    return all(s1[0] == s for s in s1) and all(s2[0] == s for s in s2)
+
+
+def loss_of_one_batch(batch, model, criterion, device, symmetrize_batch=False, use_amp=False, ret=None):
+    """dust3r/inference.py:58-79 (pairwise DUSt3R model call; the DUSt3R network itself is not part of Geo4D)."""
+    view1, view2 = batch
+    skip = {"depthmap", "dataset", "label", "instance", "idx", "true_shape", "rng"}
+    for view in batch:
+        for name in list(view.keys()):
+            if name not in skip and isinstance(view[name], torch.Tensor):
+                view[name] = view[name].to(device, non_blocking=True)
+    if symmetrize_batch:
+        view1, view2 = make_batch_symmetric(batch)
+    pred1, pred2 = model(view1, view2)
+    loss = criterion(view1, view2, pred1, pred2) if criterion is not None else None
+    result = dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=loss)
+    return result[ret] if ret else result
+
+
+@torch.no_grad()
+def inference(pairs, model, device, batch_size=8, verbose=True):
+    """dust3r/inference.py:82-101."""
+    raise NotImplementedError("dust3r pairwise inference needs the DUSt3R/CroCo network, which Geo4D does not ship "
+                              "(dust3r/model.py imports the un-vendored `croco`); kept as a named entry point only")
+
+
+def get_pred_pts3d(gt, pred, use_pose=False):
+    """dust3r/inference.py:110-132 (point-map branch)."""
+    if "pts3d" in pred:
+        return pred["pts3d"]
+    if "pts3d_in_other_view" in pred:
+        assert use_pose is True
+        return pred["pts3d_in_other_view"]
+    raise NotImplementedError("depth + pseudo_focal unprojection is part of the DUSt3R head, not of Geo4D")
+
+
+def find_opt_scaling(gt_pts1, gt_pts2, pr_pts1, pr_pts2=None, fit_mode="weiszfeld_stop_grad", valid1=None, valid2=None):
+    """dust3r/inference.py:135-179: scale s minimising |pr - s*gt| (avg / median / Weiszfeld IRLS)."""
+    def nan_invalid(x, valid):
+        if x is None:
+            return None
+        x = x.clone()
+        if valid is not None:
+            x[~valid] = float("nan")
+        return x.flatten(1, 2)
+    g = [t for t in (nan_invalid(gt_pts1, valid1), nan_invalid(gt_pts2, valid2)) if t is not None]
+    p = [t for t in (nan_invalid(pr_pts1, valid1), nan_invalid(pr_pts2, valid2)) if t is not None]
+    all_gt, all_pr = torch.cat(g, dim=1), torch.cat(p, dim=1)
+    dot_gp, dot_gg = (all_pr * all_gt).sum(-1), all_gt.square().sum(-1)
+    if fit_mode.startswith("avg"):
+        s = dot_gp.nanmean(1) / dot_gg.nanmean(1)
+    elif fit_mode.startswith("median"):
+        s = (dot_gp / dot_gg).nanmedian(1).values
+    elif fit_mode.startswith("weiszfeld"):
+        s = dot_gp.nanmean(1) / dot_gg.nanmean(1)
+        for _ in range(10):
+            w = (all_pr - s.view(-1, 1, 1) * all_gt).norm(dim=-1).clip_(min=1e-8).reciprocal()
+            s = (w * dot_gp).nanmean(1) / (w * dot_gg).nanmean(1)
+    else:
+        raise ValueError(f"bad {fit_mode=}")
+    if fit_mode.endswith("stop_grad"):
+        s = s.detach()
+    return s.clip(min=1e-3)

@@ -48,10 +48,72 @@ def _ld(t):
     return t.stride(0)
 
 
+_WS = {}
+WORKSPACE_BYTES = 256 << 20
+
+# ---- per-shape launch tuning ------------------------------------------------------------------------------------
+# geo4d_conv_gemm has 5 tile shapes x split-K factors; the C-side heuristic is a fallback. The host keeps a table
+# problem-signature -> (tile_hint, split_k): loaded from geo4d_amd/tuning/gfx950.json (measured on MI355X by
+# tools/tune_gemm.py) and, for shapes not in it, filled by timing the candidates on first eager use (never while a
+# hipGraph is being captured). Every candidate computes the same sums in the same k order per output element
+# (split-K only regroups them), so tuning never changes results beyond fp32 re-association.
+import json as _json
+import os as _os
+
+_TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950.json")
+_TUNE = None
+_CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (1, 2), (1, 4), (1, 8), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
+AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
+
+
+def _tune_table():
+    global _TUNE
+    if _TUNE is None:
+        _TUNE = {}
+        if _os.path.exists(_TUNE_PATH):
+            with open(_TUNE_PATH) as f:
+                _TUNE = {k: tuple(v) for k, v in _json.load(f).items()}
+    return _TUNE
+
+
+def save_tuning(path=None):
+    with open(path or _TUNE_PATH, "w") as f:
+        _json.dump({k: list(v) for k, v in sorted(_tune_table().items())}, f, indent=0)
+
+
+def _autotune(launch, key):
+    best, best_t = (0, 0), float("inf")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for tile, split in _CANDIDATES:
+        try:
+            launch(tile, split)
+        except RuntimeError:
+            continue
+        e0.record()
+        for _ in range(3):
+            launch(tile, split)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = (tile, split), t
+    _tune_table()[key] = best
+    return best
+
+
+def workspace(device):
+    """One static fp32 scratch per device for split-K slabs (stream-ordered reuse; allocated outside graph capture)."""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = _WS[device] = (torch.empty(WORKSPACE_BYTES, device=device, dtype=torch.uint8),
+                            torch.zeros(256, device=device, dtype=torch.uint8))
+    return ws
+
+
 def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout=1, Wout=1, KT=1, KH=1, KW=1,
               pt=0, ph=0, pw=0, stride=1, ups=1, bias=None, bias_per_row=False, rowbias=None, rowbias_div=0,
               residual=None, ldr=0, act=0, out_nchw=False, alpha=1.0, batch=1, a_bs=0, w_bs=0, o_bs=0, r_bs=0,
-              tile_hint=0):
+              tile_hint=0, split_k=0):
     lib = _lib.load()
     _dev(a, "A"); _dev(w, "W"); _dev(out, "out")
     assert a.dtype == w.dtype, (a.dtype, w.dtype)
@@ -72,12 +134,25 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.KT, p.KH, p.KW, p.pt, p.ph, p.pw, p.stride, p.ups = KT, KH, KW, pt, ph, pw, stride, ups
     p.rowbias_div, p.bias_per_row, p.act = rowbias_div, int(bias_per_row), act
     p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = dt_code(a.dtype), dt_code(out.dtype), int(out_nchw), tile_hint
-    p.alpha = alpha
-    _lib.check(lib.geo4d_conv_gemm(C.byref(p), _stream()), "geo4d_conv_gemm")
+    p.alpha, p.split_k = alpha, split_k
+    ws, zeros = workspace(a.device)
+    p.workspace, p.workspace_bytes, p.zeros = ws.data_ptr(), ws.numel(), zeros.data_ptr()
+
+    def launch(tile, split):
+        p.tile_hint, p.split_k = tile, split
+        _lib.check(lib.geo4d_conv_gemm(C.byref(p), _stream()), "geo4d_conv_gemm")
+
+    if tile_hint == 0 and split_k == 0:
+        key = f"{p.dtype}/{p.out_dtype}|{M}x{N}x{K}|c{Cin}|t{KT}{KH}{KW}s{stride}u{ups}|a{act}r{int(residual is not None)}n{int(out_nchw)}|b{batch}"
+        cfg = _tune_table().get(key)
+        if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            cfg = _autotune(launch, key)
+        tile_hint, split_k = cfg if cfg is not None else (0, 0)
+    launch(tile_hint, split_k)
     return out
 
 
-def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0):
+def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0, split_k=0):
     """x [M, K] (row pitch free), w packed [N, K]; GEGLU (act=2) returns [M, N/2]."""
     M, K = x.shape
     N = w.shape[0]
@@ -86,11 +161,11 @@ def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, a
         out = torch.empty((M, N // 2 if act == 2 else N), device=x.device, dtype=out_dtype or x.dtype)
     return conv_gemm(x, w, out, M=M, N=N, K=K, Cin=K, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), bias=bias,
                      residual=residual, ldr=_ld(residual) if residual is not None else 0, act=act, alpha=alpha,
-                     tile_hint=tile_hint)
+                     tile_hint=tile_hint, split_k=split_k)
 
 
 def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, ups=1, T=1, rowbias=None, rowbias_div=0,
-           residual=None, act=0, out=None, out_dtype=None, out_nchw=False, nchw_channels=None, tile_hint=0):
+           residual=None, act=0, out=None, out_dtype=None, out_nchw=False, nchw_channels=None, tile_hint=0, split_k=0):
     """x tokens [F*Hin*Win, Cin]; w packed [N, KH*KW*Cin]. Output tokens [F*Hout*Wout, N], or with out_nchw a
     [B, C, T, Hout, Wout] tensor (`out` may be a channel-offset view of a wider tensor with `nchw_channels` channels)."""
     Cin = x.shape[1]
@@ -109,7 +184,8 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, ups=1, T=1, rowb
     conv_gemm(x, w, out, M=M, N=N, K=KH * KW * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=(nchw_channels or N) if out_nchw else _ld(out), T=T,
               Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=KH, KW=KW, ph=pad, pw=pad, stride=stride, ups=ups, bias=bias,
               rowbias=rowbias, rowbias_div=rowbias_div, residual=residual,
-              ldr=_ld(residual) if residual is not None else 0, act=act, out_nchw=out_nchw, tile_hint=tile_hint)
+              ldr=_ld(residual) if residual is not None else 0, act=act, out_nchw=out_nchw, tile_hint=tile_hint,
+              split_k=split_k)
     return out, Hout, Wout
 
 

@@ -36,6 +36,9 @@ typedef struct geo4d_conv_gemm_t {
     const float* bias;   /* [N] (or [M] when bias_per_row), may be NULL                 */
     const float* rowbias;/* [M/rowbias_div][N] fp32 added per row group, may be NULL    */
     const void* R;       /* residual [M][ldr], dtype = out_dtype, may be NULL           */
+    const void* zeros;   /* >= 16 zero bytes in device memory (source of padding taps)  */
+    void* workspace;     /* fp32 scratch for split-K slabs (caller-owned, may be NULL)  */
+    size_t workspace_bytes;
     long lda, ldw, ldo, ldr;
     long ldrb;           /* row pitch of rowbias in floats (0 = N)                      */
     long a_bs, w_bs, o_bs, r_bs; /* batch strides in elements (batched GEMM)            */
@@ -51,6 +54,7 @@ typedef struct geo4d_conv_gemm_t {
     int out_nchw;        /* 1: store O as [B][ldo][T][Hout*Wout] (ldo = channel count of the
                             destination tensor; O may point at a channel offset inside it) */
     int tile_hint;       /* 0 auto, 1..5 force a tile configuration (tests)             */
+    int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
     float alpha;
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);

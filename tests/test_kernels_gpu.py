@@ -282,3 +282,26 @@ def test_ddim_step(dev):
     check("ddim x_prev", x, 0.7 * p0 + 0.5 * e_t + 0.1 * nz, torch.float32)
     ops.advance_index(idx, -1)
     assert idx.item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("split", [2, 4])
+def test_split_k_conv_matches(dev, dtype, split):
+    """Deep-K, small-M problems (5x8 / 10x16 U-Net levels) run split-K: fp32 slabs + fixed-order reduce with the epilogue."""
+    from geo4d_amd import ops, pack
+    F, H, W, Ci, Co = 2, 5, 8, 256, 96
+    x_nchw = rnd((F, Ci, H, W), dev, dtype, 50)
+    w = rnd((Co, Ci, 3, 3), dev, torch.float32, 51, 0.03)
+    b = rnd((Co,), dev, torch.float32, 52)
+    emb = rnd((F, Co), dev, torch.float32, 53)
+    x = x_nchw.permute(0, 2, 3, 1).reshape(F * H * W, Ci).contiguous()
+    res = rnd((F * H * W, Co), dev, dtype, 54)
+    wp = pack.pack_conv2d(w, dtype)
+    out, _, _ = ops.conv2d(x, wp, b, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, rowbias=emb, rowbias_div=H * W, residual=res, split_k=split)
+    one, _, _ = ops.conv2d(x, wp, b, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, rowbias=emb, rowbias_div=H * W, residual=res, split_k=1)
+    ref = TF.conv2d(x_nchw.float(), w.to(dtype).float(), b, padding=1) + emb[:, :, None, None]
+    ref = ref.permute(0, 2, 3, 1).reshape(F * H * W, Co) + res.float()
+    check(f"split-k {split}", out, ref, dtype)
+    check(f"split-k {split} vs unsplit", out, one.float(), dtype)
+    again, _, _ = ops.conv2d(x, wp, b, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, rowbias=emb, rowbias_div=H * W, residual=res, split_k=split)
+    assert torch.equal(out, again), "split-K reduce must be deterministic"

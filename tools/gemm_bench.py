@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--filter", default="")
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     dev = torch.device("cuda:0")
@@ -69,30 +71,43 @@ def main():
             w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
             b = torch.randn((N,), device=dev)
             r = torch.randn((M, N), device=dev).to(dt)
-            fn = lambda: ops.conv2d(x, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=r, tile_hint=args.tile)
+            fn = lambda tile=args.tile, split=args.split: ops.conv2d(x, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=r, tile_hint=tile, split_k=split)
         elif kind == "t3":
             T, HW = geo
             M, K = T * HW, 3 * Cin
             x = torch.randn((M, Cin), device=dev).to(dt)
             w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
             b = torch.randn((N,), device=dev)
-            fn = lambda: ops.conv_temporal(x, w, b, B=1, T=T, HW=HW, residual=x)
+            fn = lambda tile=args.tile, split=args.split: ops.conv_gemm(x, w, torch.empty((M, N), device=dev, dtype=dt), M=M, N=N, K=K, Cin=Cin, lda=Cin, ldw=K, ldo=N, T=T, Hin=HW, Win=1, Hout=HW, Wout=1, KT=3, pt=1, bias=b, residual=x, ldr=Cin, tile_hint=tile, split_k=split)
         else:
             M, K = geo, Cin
             x = torch.randn((M, K), device=dev).to(dt)
             w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
             b = torch.randn((N,), device=dev)
             act = 2 if kind == "geglu" else 0
-            fn = lambda: ops.linear(x, w, b, act=act, tile_hint=args.tile)
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / args.iters
+            fn = lambda tile=args.tile, split=args.split: ops.linear(x, w, b, act=act, tile_hint=tile, split_k=split)
+        def timeit(**kw):
+            for _ in range(2):
+                fn(**kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn(**kw)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / args.iters
+        us = timeit()
+        if args.explore:
+            res = []
+            for tile in (1, 2, 3, 4):
+                for split in (1, 2, 4, 8):
+                    try:
+                        res.append((timeit(tile=tile, split=split), tile, split))
+                    except RuntimeError:
+                        pass
+            res.sort()
+            print("    auto %.1f us | best: %s" % (us, "  ".join("t%d/s%d %.1f" % (t, s2, u) for u, t, s2 in res[:4])))
+            us = min(us, res[0][0])
         tf = 2.0 * M * N * K / us / 1e6
         tot_ms += us * cnt / 1e3
         tot_tf += 2.0 * M * N * K * cnt / 1e12

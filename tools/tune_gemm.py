@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Fill geo4d_amd/tuning/gfx950.json on a GPU box: run one eager U-Net forward + one 4-modality decode at the bench
+configuration (and at the test configurations) with autotuning on, then save the table. Copy the printed JSON back
+(gpurun merges gpurun_out/)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from geo4d_amd import ops  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "gfx950.json")
+    dev = torch.device("cuda:0")
+    for dtype in (sys.argv[2:] or ["bf16"]):
+        model, pvae = bench.build(dtype, dev)
+        T, h, w = 16, 40, 64
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn((1, 16, T, h, w), generator=g).to(dev)
+        zc = torch.randn((1, 4, T, h, w), generator=g).to(dev)
+        ctx = torch.randn((1, 77 + 16 * T, 1024), generator=g).to(dev)
+        t = torch.tensor([500], device=dev)
+        y = model.apply_model(x, t, {"c_crossattn": [ctx], "c_concat": [zc]}, fs=torch.tensor([24], device=dev))
+        from geo4d_amd.pipeline import decode_modalities
+        decode_modalities(model, y, pvae)
+        torch.cuda.synchronize()
+        del model, pvae
+    ops.save_tuning(out)
+    print("saved", len(ops._tune_table()), "entries to", out)
+
+
+if __name__ == "__main__":
+    main()
