@@ -35,7 +35,7 @@ class ConvGemm(C.Structure):
         ("stride", C.c_int), ("ups", C.c_int),
         ("rowbias_div", C.c_int), ("bias_per_row", C.c_int), ("act", C.c_int),
         ("dtype", C.c_int), ("out_dtype", C.c_int), ("out_nchw", C.c_int), ("tile_hint", C.c_int),
-        ("split_k", C.c_int), ("alpha", C.c_float),
+        ("split_k", C.c_int), ("debug_ablate", C.c_int), ("alpha", C.c_float),
     ]
 
 

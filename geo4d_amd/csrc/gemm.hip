@@ -48,18 +48,18 @@ __device__ __forceinline__ float load_res(const void* R, long idx, int dt) {
     return f16_bits_to_f32(((const unsigned short*)R)[idx]);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ST>
 constexpr int stage_bytes() {
-    constexpr int ring = 2 * (BM + BN) * PITCH;
+    constexpr int ring = ST * (BM + BN) * PITCH;
     constexpr int epi = 4 * (BM / WM) * (BN / WN + 4) * 4;   // fp32 transpose tiles of the 4 waves
     return ring > epi ? ring : epi;
 }
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ST>
 constexpr int smem_bytes() {
-    return stage_bytes<BM, BN, WM, WN>() + BM * MAXTAP * 4;
+    return stage_bytes<BM, BN, WM, WN, ST>() + BM * MAXTAP * 4;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int ST>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = BKC * EPC;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
     static_assert(WM * WN == 4, "4 waves");
     static_assert(MB >= 1 && NB >= 1 && ACH >= 1 && BCH >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* rowpix = (int*)(smem + stage_bytes<BM, BN, WM, WN>());
+    int* rowpix = (int*)(smem + stage_bytes<BM, BN, WM, WN, ST>());
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
@@ -174,29 +174,64 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
 #pragma unroll
     for (int kk = 0; kk < BKC / 2; ++kk) foff[kk] = li * PITCH + (((2 * kk + g) ^ ((li >> 1) & 7)) << 4);
 
-    if (nslab > 0) {
-        fetch_pix();
-        issue_slab(0);
-    }
-    __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nslab) issue_slab(buf ^ 1);
-        const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
-        const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
-#pragma unroll
-        for (int kk = 0; kk < BKC / 2; ++kk) {
-            u32x4 fa[MB], fb[NB];
-#pragma unroll
-            for (int a = 0; a < MB; ++a) fa[a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[kk]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) fb[b] = *(const u32x4*)(bbase + b * 32 * PITCH + foff[kk]);
-#pragma unroll
-            for (int a = 0; a < MB; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fb[b], fa[a]);   // C rows = n, C cols = m
+    if constexpr (ST == 2) {
+        if (nslab > 0) {
+            fetch_pix();
+            issue_slab(0);
         }
-        __syncthreads();   // next stage landed (vmcnt(0)) and every wave is done reading this one
+        __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+        for (int s = 0; s < nslab; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nslab && !(p.debug_ablate & 1)) issue_slab(buf ^ 1);
+            const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
+            const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
+            if (!(p.debug_ablate & 2))
+#pragma unroll
+            for (int kk = 0; kk < BKC / 2; ++kk) {
+                u32x4 fa[MB], fb[NB];
+#pragma unroll
+                for (int a = 0; a < MB; ++a) fa[a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[kk]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) fb[b] = *(const u32x4*)(bbase + b * 32 * PITCH + foff[kk]);
+#pragma unroll
+                for (int a = 0; a < MB; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fb[b], fa[a]);   // C rows = n, C cols = m
+            }
+            __syncthreads();   // next stage landed (vmcnt(0)) and every wave is done reading this one
+        }
+    } else {
+        // 3-deep ring, DMA two stages ahead, ONE barrier per stage, counted vmcnt (never 0 in the steady state):
+        //   wait(stage s landed: at most the ACH+BCH DMAs of stage s+1 still in flight) -> barrier (everyone's part of
+        //   stage s landed, everyone finished reading stage s-1) -> issue stage s+2 into the buffer of s-1 -> compute s
+        if (nslab > 0) {
+            fetch_pix();
+            issue_slab(0);
+            if (nslab > 1) issue_slab(1);
+        }
+        int buf = 0;
+        for (int s = 0; s < nslab; ++s) {
+            if (s + 1 < nslab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ACH + BCH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + 2 < nslab) issue_slab(buf == 0 ? 2 : buf - 1);
+            const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
+            const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
+#pragma unroll
+            for (int kk = 0; kk < BKC / 2; ++kk) {
+                u32x4 fa[MB], fb[NB];
+#pragma unroll
+                for (int a = 0; a < MB; ++a) fa[a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[kk]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) fb[b] = *(const u32x4*)(bbase + b * 32 * PITCH + foff[kk]);
+#pragma unroll
+                for (int a = 0; a < MB; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fb[b], fa[a]);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        __syncthreads();   // all waves done with the ring before the epilogue reuses it
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
@@ -389,11 +424,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const geo4d_conv_gem
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int ST>
 int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
-    constexpr int smem = smem_bytes<BM, BN, WM, WN>();
+    constexpr int smem = smem_bytes<BM, BN, WM, WN, ST>();
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<T, BM, BN, WM, WN>;
+    auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, ST>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
@@ -426,10 +461,11 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     const bool can_split = p.workspace && p.act != 2 && !p.out_nchw && (p.N % 8) == 0 && p.split_k != 1;
     int best = -1, best_split = 1;
     float best_score = -1.f;
+    const int hint_tile = p.tile_hint > 5 ? p.tile_hint - 5 : p.tile_hint;   // hints 6..10 = same tiles, 3-stage ring
     for (int i = 0; i < 5; ++i) {
         const TileCfg& c = cfgs[i];
         if (p.act == 2 && i >= 3) continue;  // GEGLU needs 64-wide wave tiles (NB == 2)
-        if (p.tile_hint && i != p.tile_hint - 1) continue;
+        if (hint_tile && i != hint_tile - 1) continue;
         const double tm = (p.M + c.bm - 1) / c.bm, tn = (p.N + c.bn - 1) / c.bn;
         const double tiles = tm * tn * p.batch;
         const double useful = ((double)p.M * p.N * p.batch) / (tiles * c.bm * c.bn);
@@ -445,12 +481,21 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             if (score > best_score) { best_score = score; best = i; best_split = s; }
         }
     }
+    if (p.tile_hint > 5) {
+        switch (best) {
+            case 0: return launch_cfg<T, 128, 128, 2, 2, 3>(p, best_split, stream);
+            case 1: return launch_cfg<T, 128, 64, 4, 1, 3>(p, best_split, stream);
+            case 2: return launch_cfg<T, 64, 128, 2, 2, 3>(p, best_split, stream);
+            case 3: return launch_cfg<T, 64, 64, 2, 2, 3>(p, best_split, stream);
+            case 4: return launch_cfg<T, 128, 32, 4, 1, 3>(p, best_split, stream);
+        }
+    }
     switch (best) {
-        case 0: return launch_cfg<T, 128, 128, 2, 2>(p, best_split, stream);
-        case 1: return launch_cfg<T, 128, 64, 4, 1>(p, best_split, stream);
-        case 2: return launch_cfg<T, 64, 128, 2, 2>(p, best_split, stream);
-        case 3: return launch_cfg<T, 64, 64, 2, 2>(p, best_split, stream);
-        case 4: return launch_cfg<T, 128, 32, 4, 1>(p, best_split, stream);
+        case 0: return launch_cfg<T, 128, 128, 2, 2, 2>(p, best_split, stream);
+        case 1: return launch_cfg<T, 128, 64, 4, 1, 2>(p, best_split, stream);
+        case 2: return launch_cfg<T, 64, 128, 2, 2, 2>(p, best_split, stream);
+        case 3: return launch_cfg<T, 64, 64, 2, 2, 2>(p, best_split, stream);
+        case 4: return launch_cfg<T, 128, 32, 4, 1, 2>(p, best_split, stream);
     }
     geo4d_set_error("conv_gemm: no tile configuration (split_k / tile_hint not applicable to this problem?)");
     return GEO4D_EINVAL;

@@ -46,12 +46,20 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 #pragma unroll
         for (int j = 0; j < EPC; ++j) { s[j] = 0.f; q[j] = 0.f; }
         if (active && cc < CPR) {
-            for (int r = tr; r < rows; r += TR) {
-                const u32x4 v = *(const u32x4*)(base + (long)r * ldx + cc * EPC);
-                float e[EPC];
-                chunk_to_f32<T>(v, e);
+            for (int r = tr; r < rows; r += 4 * TR) {
+                u32x4 v[4];
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) { s[j] += e[j]; q[j] += e[j] * e[j]; }
+                for (int u = 0; u < 4; ++u) {   // 4 independent 16-byte loads in flight per lane
+                    const int ru = r + u * TR;
+                    v[u] = ru < rows ? *(const u32x4*)(base + (long)ru * ldx + cc * EPC) : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float e[EPC];
+                    chunk_to_f32<T>(v[u], e);
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) { s[j] += e[j]; q[j] += e[j] * e[j]; }
+                }
             }
         }
 #pragma unroll
@@ -85,41 +93,43 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 }
 
 // ---- GroupNorm pass 2: merge partials -> (mean, rstd) per (stat, group) --------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int fps, int G,
-                                                          float eps, float* __restrict__ stats) {
-    // 256 threads: 8 lanes per group merge strided subsets, then lane 0 merges the 8 results in order.
-    __shared__ double sh[256][3];
-    const int tid = threadIdx.x;
-    const int grp = tid >> 3, sub = tid & 7;
-    const int stat = blockIdx.x;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    if (grp < G) {
-        const int total = fps * nchunk;
-        for (int i = sub; i < total; i += 8) {
-            const float* pp = part + (((long)stat * fps * nchunk + i) * G + grp) * 3;
-            const double nb = pp[0], mb = pp[1], qb = pp[2];
-            const double nn = n + nb;
-            const double d = mb - mean;
-            mean += d * nb / nn;
-            m2 += qb + d * d * n * nb / nn;
-            n = nn;
-        }
+// one wave per (stat, group): lanes merge strided subsets with Chan's formula, then a fixed-order xor-butterfly merges
+// the 64 lane results (deterministic: the pairing does not depend on timing)
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float qb) {
+    if (nb > 0.f) {
+        const float nn = n + nb;
+        const float d = mb - mean;
+        const float w = nb / nn;
+        mean += d * w;
+        m2 += qb + d * d * n * w;
+        n = nn;
     }
-    sh[tid][0] = n; sh[tid][1] = mean; sh[tid][2] = m2;
-    __syncthreads();
-    if (grp < G && sub == 0) {
-        for (int k = 1; k < 8; ++k) {
-            const double nb = sh[tid + k][0], mb = sh[tid + k][1], qb = sh[tid + k][2];
-            if (nb == 0.0) continue;
-            const double nn = n + nb;
-            const double d = mb - mean;
-            mean += d * nb / nn;
-            m2 += qb + d * d * n * nb / nn;
-            n = nn;
-        }
-        const double var = m2 / n;
-        stats[((long)stat * G + grp) * 2 + 0] = (float)mean;
-        stats[((long)stat * G + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int fps, int G,
+                                                          float eps, float* __restrict__ stats, int nstat) {
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= nstat * G) return;
+    const int stat = unit / G, grp = unit - stat * G;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    const int total = fps * nchunk;
+    for (int i = lane; i < total; i += 64) {
+        const float* pp = part + (((long)stat * total + i) * G + grp) * 3;
+        chan_merge(n, mean, m2, pp[0], pp[1], pp[2]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
+        // both partners must compute the same merged value: order the pair by lane id
+        float n0 = n, a0 = mean, q0 = m2, n1 = nb, a1 = mb, q1 = qb;
+        if (lane & o) { n0 = nb; a0 = mb; q0 = qb; n1 = n; a1 = mean; q1 = m2; }
+        chan_merge(n0, a0, q0, n1, a1, q1);
+        n = n0; mean = a0; m2 = q0;
+    }
+    if (lane == 0) {
+        const float var = m2 / n;
+        stats[((long)stat * G + grp) * 2 + 0] = mean;
+        stats[((long)stat * G + grp) * 2 + 1] = 1.0f / sqrtf(var + eps);
     }
 }
 
@@ -153,17 +163,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             sc[j] = rstd * gamma[c];
             sh[j] = beta[c] - mean * sc[j];
         }
-        for (int r = tr; r < rows; r += TR) {
-            const u32x4 v = *(const u32x4*)(xb + (long)r * ldx + cc * EPC);
-            float e[EPC];
-            chunk_to_f32<T>(v, e);
+        for (int r = tr; r < rows; r += 4 * TR) {
+            u32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < EPC; ++j) {
-                float o = e[j] * sc[j] + sh[j];
-                if (act == 1) o = silu_f(o);
-                e[j] = o;
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + u * TR;
+                v[u] = ru < rows ? *(const u32x4*)(xb + (long)ru * ldx + cc * EPC) : u32x4{0u, 0u, 0u, 0u};
             }
-            *(u32x4*)(yb + (long)r * ldy + cc * EPC) = f32_to_chunk<T>(e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + u * TR;
+                if (ru >= rows) break;
+                float e[EPC];
+                chunk_to_f32<T>(v[u], e);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    float o = e[j] * sc[j] + sh[j];
+                    if (act == 1) o = silu_f(o);
+                    e[j] = o;
+                }
+                *(u32x4*)(yb + (long)ru * ldy + cc * EPC) = f32_to_chunk<T>(e);
+            }
         }
     }
 }
@@ -254,8 +274,9 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
                        R, nchunk, part);
     GEO4D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.F / p.frames_per_stat), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
-                       p.groups, p.eps, stats);
+    const int nstat = p.F / p.frames_per_stat;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
+                       p.groups, p.eps, stats, nstat);
     GEO4D_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
                        p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act);

@@ -53,8 +53,9 @@ typedef struct geo4d_conv_gemm_t {
     int out_dtype;       /* O/R element type                                            */
     int out_nchw;        /* 1: store O as [B][ldo][T][Hout*Wout] (ldo = channel count of the
                             destination tensor; O may point at a channel offset inside it) */
-    int tile_hint;       /* 0 auto, 1..5 force a tile configuration (tests)             */
+    int tile_hint;       /* 0 auto, 1..5 force a tile shape (2-stage ring), 6..10 same, 3-stage */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
+    int debug_ablate;    /* profiling only: bit0 skip steady-state DMA, bit1 skip MFMA  */
     float alpha;
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);

@@ -99,14 +99,14 @@ def main():
         us = timeit()
         if args.explore:
             res = []
-            for tile in (1, 2, 3, 4):
+            for tile in (1, 2, 3, 4, 6, 7, 8, 9):
                 for split in (1, 2, 4, 8):
                     try:
                         res.append((timeit(tile=tile, split=split), tile, split))
                     except RuntimeError:
                         pass
             res.sort()
-            print("    auto %.1f us | best: %s" % (us, "  ".join("t%d/s%d %.1f" % (t, s2, u) for u, t, s2 in res[:4])))
+            print("    auto %.1f us | best: %s" % (us, "  ".join("t%d/s%d %.1f" % (t, s2, u) for u, t, s2 in res[:6])))
             us = min(us, res[0][0])
         tf = 2.0 * M * N * K / us / 1e6
         tot_ms += us * cnt / 1e3
