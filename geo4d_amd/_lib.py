@@ -52,8 +52,8 @@ class GroupNorm(C.Structure):
 class Attention(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("o", C.c_void_p),
-        ("k", C.c_void_p * 2), ("v", C.c_void_p * 2),
-        ("ldq", C.c_long), ("ldo", C.c_long), ("ldk", C.c_long * 2), ("ldv", C.c_long * 2),
+        ("k", C.c_void_p * 2), ("vt", C.c_void_p * 2), ("zeros", C.c_void_p),
+        ("ldq", C.c_long), ("ldo", C.c_long), ("ldk", C.c_long * 2), ("ldvt", C.c_long * 2), ("vt_bs", C.c_long * 2),
         ("Nk", C.c_int * 2), ("kv_div", C.c_int * 2),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("nseg", C.c_int), ("head_dim", C.c_int), ("dtype", C.c_int),
         ("scale", C.c_float),

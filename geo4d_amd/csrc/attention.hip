@@ -7,10 +7,12 @@
 //     Structure (one workgroup = 128 query rows = 4 waves x 32 rows, K/V tiles of 64 keys):
 //       - swapped QK^T: S^T = K.Q^T on MFMA 32x32, so one lane owns one query column and the softmax row
 //         reduction is in-register (one cross-half __shfl_xor(32) per tile) — wave-64 idiom, no LDS round trip;
-//       - P never leaves registers: its C-layout registers ARE the B operand of the PV MFMA
-//         (O^T = V^T.P^T); V is staged transposed in LDS so the matching A fragments are 8/16-byte reads;
-//       - K rows padded to 144 B / V^T rows to 136 B: conflict-free ds_read_b128 / ds_read_b64;
-//       - next K/V tile prefetched into registers while the current one is consumed.
+//       - P never leaves registers: its C-layout registers ARE the B operand of the PV MFMA (O^T = V^T.P^T);
+//       - V arrives already transposed ([head*64 + d][key], written that way by an operand-swapped projection GEMM), so
+//         K and V^T tiles are both plain row tiles moved by LDS-DMA (global_load_lds_dwordx4) into a 2-deep ring with a
+//         source-side XOR swizzle: no ds_write at all, next tile in flight while the current one is consumed,
+//         ONE barrier per tile;
+//       - softmax on raw scores with the scale folded into one fma + v_exp_f32 (exp2) per element.
 // (2) temporal_attn_kernel: self-attention over T <= 16 frames for every (pixel, head)
 //     (attention.py:365-412 TemporalTransformer, both attn1 and attn2). 0.02 TFLOP per forward but ~100 MB of
 //     q/k/v/o traffic per layer: HBM-bound, so plain VALU with one wave per (pixel, head) and fp32 K/V in LDS.
@@ -20,24 +22,28 @@
 
 namespace {
 
+// K tiles are [64 keys][64 d] and V^T tiles [64 d][64 keys]: both are 64 rows of 16-byte slots filled by LDS-DMA
+// (lane-linear image), XOR-swizzled on the source side (128-byte rows: slot = chunk ^ ((row >> 1) & 7) as in gemm.hip;
+// 256-byte f32 rows: slot = chunk ^ (row & 15)).
 template <typename T>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = (int)sizeof(T);
-    constexpr int DCH = 64 / EPC;                 // 16-byte chunks per 64-wide head row
-    constexpr int NKK = DCH / 2;                  // cmma steps over d
-    constexpr int KPITCH = 64 * ES + 16;
-    constexpr int VPITCH = 64 * ES + (ES == 2 ? 8 : 16);
-    constexpr int NST = 64 * DCH / 256;           // staged chunks per thread per operand
+    constexpr int SLOTS = 64 / EPC;               // 16-byte slots per 64-element row: 8 (16-bit) or 16 (f32)
+    constexpr int ROWB = 64 * ES;                 // row bytes: 128 / 256
+    constexpr int NKK = SLOTS / 2;                // cmma steps over d
+    constexpr int TILE = 64 * ROWB;               // one operand tile
+    constexpr int NDMA = TILE / 1024 / 4;         // DMA instructions per wave per operand: 2 / 4
+    constexpr int RPI = 1024 / ROWB;              // rows per DMA instruction: 8 / 4
     constexpr int PCH = 16 / EPC;                 // P chunks per 32-key block
-    __shared__ __attribute__((aligned(16))) char ktile[64 * KPITCH];
-    __shared__ __attribute__((aligned(16))) char vtile[64 * VPITCH];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];   // [buf][K | Vt]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
     const int qrow = blockIdx.x * 128 + wave * 32 + li;
     const bool qok = qrow < p.Nq;
+    const T* __restrict__ Z = (const T*)p.zeros;
 
     u32x4 qf[NKK];
     {
@@ -54,61 +60,47 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { of[d][r] = 0.f; oa[d][r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;       // running max of RAW scores; sums of exp2((s - m) * c)
+    const float c2 = p.scale * 1.4426950408889634f;
 
-    u32x4 kreg[NST], vreg[NST];
-    auto load_tile = [&](int seg, int tile) {
-        // explicit selects: dynamic indexing of kernel-argument arrays would spill them to scratch
+    // staging geometry of this lane: DMA instruction i of this wave covers rows (wave*NDMA + i)*RPI .. +RPI
+    const int srow = lane / SLOTS, sslot = lane % SLOTS;
+    auto issue_tile = [&](int seg, int tile, int buf) {
         const int nk = seg ? p.Nk[1] : p.Nk[0];
-        const long ldk = seg ? p.ldk[1] : p.ldk[0], ldv = seg ? p.ldv[1] : p.ldv[0];
+        const long ldk = seg ? p.ldk[1] : p.ldk[0], ldvt = seg ? p.ldvt[1] : p.ldvt[0];
         const long kvb = b / (seg ? p.kv_div[1] : p.kv_div[0]);
         const T* kp = (const T*)(seg ? p.k[1] : p.k[0]) + kvb * nk * ldk + h * 64;
-        const T* vp = (const T*)(seg ? p.v[1] : p.v[0]) + kvb * nk * ldv + h * 64;
+        const T* vp = (const T*)(seg ? p.vt[1] : p.vt[0]) + kvb * (seg ? p.vt_bs[1] : p.vt_bs[0]) + (long)h * 64 * ldvt;
+        char* kb_ = lds + buf * 2 * TILE;
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / DCH, col = idx % DCH;
+        for (int i = 0; i < NDMA; ++i) {
+            const int row = (wave * NDMA + i) * RPI + srow;            // key index in tile / d index
+            const int chunk = sslot ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15));   // logical 16-byte chunk fetched into this slot
             const int key = tile * 64 + row;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (key < nk) {
-                kv = *(const u32x4*)(kp + (long)key * ldk + col * EPC);
-                vv = *(const u32x4*)(vp + (long)key * ldv + col * EPC);
-            }
-            kreg[i] = kv;
-            vreg[i] = vv;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / DCH, col = idx % DCH;
-            *(u32x4*)(ktile + row * KPITCH + col * 16) = kreg[i];
-            if constexpr (ES == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    *(unsigned short*)(vtile + (col * 8 + 2 * j) * VPITCH + row * 2) = (unsigned short)(vreg[i][j] & 0xffffu);
-                    *(unsigned short*)(vtile + (col * 8 + 2 * j + 1) * VPITCH + row * 2) = (unsigned short)(vreg[i][j] >> 16);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *(unsigned int*)(vtile + (col * 4 + j) * VPITCH + row * 4) = vreg[i][j];
-            }
+            const T* ks = key < nk ? kp + (long)key * ldk + chunk * EPC : Z;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                             (__attribute__((address_space(3))) void*)(kb_ + (wave * NDMA + i) * 1024), 16, 0, 0);
+            const int key0 = tile * 64 + chunk * EPC;                   // first key of this V^T chunk (row = d)
+            const T* vs = key0 < nk ? vp + (long)row * ldvt + key0 : Z;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                             (__attribute__((address_space(3))) void*)(kb_ + TILE + (wave * NDMA + i) * 1024), 16, 0, 0);
         }
     };
 
-    int seg = 0, tile = 0;
-    load_tile(0, 0);
+    // swizzled fragment offsets (row li of a 32-row block; (li >> 1) & (SLOTS-1) is block independent)
+    const int swz = ES == 2 ? ((li >> 1) & 7) : (li & 15);   // 128-byte rows: 2 rows per bank row; 256-byte rows: 1
+    int seg = 0, tile = 0, buf = 0;
+    issue_tile(0, 0, 0);
     while (true) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
+        __syncthreads();                         // DMA of this tile landed (vmcnt(0)); everyone finished the previous tile
         const int nk = seg ? p.Nk[1] : p.Nk[0];
         const int ntile = (nk + 63) >> 6;
         int nseg2 = seg, ntile2 = tile + 1;
         if (ntile2 >= ntile) { nseg2 = seg + 1; ntile2 = 0; }
         const bool has_next = nseg2 < p.nseg;
-        if (has_next) load_tile(nseg2, ntile2);
+        if (has_next) issue_tile(nseg2, ntile2, buf ^ 1);      // flies while this tile is consumed
+        const char* ktile = lds + buf * 2 * TILE;
+        const char* vtile = ktile + TILE;
 
         // ---- S^T = K.Q^T --------------------------------------------------------------------
         f32x16 st[2];
@@ -118,30 +110,31 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                const u32x4 a = *(const u32x4*)(ktile + (kb * 32 + li) * KPITCH + (2 * kk + g) * 16);
+                const u32x4 a = *(const u32x4*)(ktile + (kb * 32 + li) * ROWB + (((2 * kk + g) ^ swz) << 4));
                 cmma<T>(st[kb], a, qf[kk]);
             }
         }
-        // ---- online softmax (row = this lane's query; keys live in registers) ----------------
+        // ---- online softmax on raw scores; exp2 with the scale folded in ----------------------
         float mt = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = tile * 64 + kb * 32 + acc_row(r, g);
-                const float s = key < nk ? st[kb][r] * p.scale : -INFINITY;
-                st[kb][r] = s;
-                mt = fmaxf(mt, s);
+                const float sv = key < nk ? st[kb][r] : -INFINITY;
+                st[kb][r] = sv;
+                mt = fmaxf(mt, sv);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = exp2f((m_run - m_new) * c2);
+        const float mc = m_new * c2;
         float ls = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(st[kb][r] - m_new);
+                const float e = exp2f(fmaf(st[kb][r], c2, -mc));
                 st[kb][r] = e;
                 ls += e;
             }
@@ -163,13 +156,15 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     u32x4 a;
-                    const char* vrow = vtile + (d * 32 + li) * VPITCH;
+                    const char* vrow = vtile + (d * 32 + li) * ROWB;
                     if constexpr (ES == 2) {
-                        const u32x2 lo = *(const u32x2*)(vrow + (kb * 32 + 16 * c + 4 * g) * 2);
-                        const u32x2 hi = *(const u32x2*)(vrow + (kb * 32 + 16 * c + 8 + 4 * g) * 2);
+                        // keys kb*32 + 16c + 4g + {0..3} and +8: byte offset 64kb + 32c + 8g (+16): slots 4kb + 2c (+1), half g
+                        const u32x2 lo = *(const u32x2*)(vrow + (((4 * kb + 2 * c) ^ swz) << 4) + 8 * g);
+                        const u32x2 hi = *(const u32x2*)(vrow + (((4 * kb + 2 * c + 1) ^ swz) << 4) + 8 * g);
                         a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
                     } else {
-                        a = *(const u32x4*)(vrow + (kb * 32 + 8 * c + 4 * g) * 4);
+                        // keys kb*32 + 8c + 4g + {0..3}: slot 8kb + 2c + g
+                        a = *(const u32x4*)(vrow + (((8 * kb + 2 * c + g) ^ swz) << 4));
                     }
                     cmma<T>(oa[d], a, bch);
                 }
@@ -188,6 +183,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
         if (!has_next) break;
         seg = nseg2;
         tile = ntile2;
+        buf ^= 1;
     }
     if (qok) {
         T* op = (T*)p.o + ((long)b * p.Nq + qrow) * p.ldo + h * 64;
@@ -325,11 +321,13 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     if (p.head_dim != 64) { geo4d_set_error("attention: only d_head = 64 is built (yaml num_head_channels: 64)"); return GEO4D_ENOTSUP; }
     if ((p.ldq * esz) % 16 || (p.ldo * esz) % 16 || ((uintptr_t)p.q % 16) || ((uintptr_t)p.o % 16)) { geo4d_set_error("attention: q/o alignment"); return GEO4D_EINVAL; }
     for (int s = 0; s < p.nseg; ++s) {
-        if (p.Nk[s] <= 0 || p.kv_div[s] <= 0 || !p.k[s] || !p.v[s] || (p.ldk[s] * esz) % 16 || (p.ldv[s] * esz) % 16 || ((uintptr_t)p.k[s] % 16) || ((uintptr_t)p.v[s] % 16)) {
+        if (p.Nk[s] <= 0 || p.kv_div[s] <= 0 || !p.k[s] || !p.vt[s] || (p.ldk[s] * esz) % 16 || (p.ldvt[s] * esz) % 16 || (p.vt_bs[s] * esz) % 16 ||
+            ((uintptr_t)p.k[s] % 16) || ((uintptr_t)p.vt[s] % 16) || p.ldvt[s] * (16 / esz) < 0 || ((p.Nk[s] + 16 / esz - 1) / (16 / esz)) * (16 / esz) > p.ldvt[s]) {
             geo4d_set_error("attention: bad key/value segment");
             return GEO4D_EINVAL;
         }
     }
+    if (!p.zeros || ((uintptr_t)p.zeros % 16)) { geo4d_set_error("attention: `zeros` must point at 16 zero bytes"); return GEO4D_EINVAL; }
     if (p.H > 65535 || p.B > 65535) { geo4d_set_error("attention: grid too large"); return GEO4D_EINVAL; }
     const dim3 grid((p.Nq + 127) / 128, p.H, p.B);
     hipStream_t st = (hipStream_t)stream;

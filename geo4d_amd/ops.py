@@ -255,7 +255,8 @@ def softmax_rows(x, scale, out_dtype):
 
 
 def attention(q, kv, *, B, H, Nq, scale, out=None):
-    """q [B*Nq, >=H*64] view; kv = list of (k, v, Nk, kv_div) with k/v [(B/kv_div)*Nk, >=H*64] views."""
+    """q [B*Nq, >=H*64] view; kv = list of (k, vt, Nk, kv_div, vt_bs): k [(B/kv_div)*Nk, >=H*64] view, vt = V TRANSPOSED
+    as a [>=H*64, ld] view (row = channel, column = key) whose batch b' starts vt_bs elements after batch b'-1."""
     lib = _lib.load()
     _dev(q, "q")
     if out is None:
@@ -263,12 +264,35 @@ def attention(q, kv, *, B, H, Nq, scale, out=None):
     p = Attention()
     p.q, p.o, p.ldq, p.ldo = q.data_ptr(), out.data_ptr(), _ld(q), _ld(out)
     assert 1 <= len(kv) <= 2
-    for i, (k, v, nk, div) in enumerate(kv):
-        assert k.dtype == q.dtype and v.dtype == q.dtype
-        p.k[i], p.v[i], p.ldk[i], p.ldv[i], p.Nk[i], p.kv_div[i] = k.data_ptr(), v.data_ptr(), _ld(k), _ld(v), nk, div
+    for i, (k, vt, nk, div, vt_bs) in enumerate(kv):
+        assert k.dtype == q.dtype and vt.dtype == q.dtype
+        p.k[i], p.vt[i], p.ldk[i], p.ldvt[i], p.vt_bs[i], p.Nk[i], p.kv_div[i] = k.data_ptr(), vt.data_ptr(), _ld(k), _ld(vt), vt_bs, nk, div
+    p.zeros = workspace(q.device)[1].data_ptr()
     p.B, p.H, p.Nq, p.nseg, p.head_dim, p.dtype, p.scale = B, H, Nq, len(kv), 64, dt_code(q.dtype), scale
     _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
     return out
+
+
+def linear_t_batched(w, x, batch, rows, dtype_align=None):
+    """Per-batch operand-swapped projection: x [batch*rows, K] -> out [batch, N, rows_pad] with out[b, n, m] =
+    sum_k w[n, k] x[b*rows + m, k]; rows_pad = rows rounded up to a 16-byte multiple (zero filled). This is V^T per frame."""
+    N, K = w.shape
+    epc = 4 if x.dtype == torch.float32 else 8
+    rp = (rows + epc - 1) // epc * epc
+    out = (torch.zeros if rp != rows else torch.empty)((batch, N, rp), device=x.device, dtype=x.dtype)
+    conv_gemm(w, x, out, M=N, N=rows, K=K, Cin=K, lda=_ld(w), ldw=_ld(x), ldo=rp, batch=batch, a_bs=0, w_bs=rows * _ld(x), o_bs=N * rp)
+    return out, rp
+
+
+def linear_t(w, x, bias=None, *, out=None, pad_cols=None):
+    """Operand-swapped projection: out[n, m] = sum_k w[n, k] * x[m, k] (+ bias[n]) -> [N, M]: the transposed layout the
+    attention kernel wants for V. `pad_cols`: allocate zero-filled columns up to this count (16-byte row alignment)."""
+    N, K = w.shape
+    M = x.shape[0]
+    if out is None:
+        cols = pad_cols or M
+        out = torch.zeros((N, cols), device=x.device, dtype=x.dtype) if cols != M else torch.empty((N, M), device=x.device, dtype=x.dtype)
+    return conv_gemm(w, x, out, M=N, N=M, K=K, Cin=K, lda=_ld(w), ldw=_ld(x), ldo=_ld(out), bias=bias, bias_per_row=True)
 
 
 def temporal_attention(q, k, v, *, B, T, HW, H, scale, out=None):

@@ -259,6 +259,9 @@ class UNetModel(ParamTree):
             for a in ("attn1", "attn2"):
                 if a == "attn2" and cross:
                     b[a + ".q"] = pack.pack_linear(sd[f"{p}.{a}.to_q.weight"], dt)
+                elif cross:      # spatial self-attention: q|k fused, V projected transposed (flash kernel wants V^T)
+                    b[a + ".qk"] = pack.pack_linear(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"]], 0), dt)
+                    b[a + ".v"] = pack.pack_linear(sd[f"{p}.{a}.to_v.weight"], dt)
                 else:
                     b[a + ".qkv"] = pack.pack_linear(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"],
                                                                 sd[f"{p}.{a}.to_v.weight"]], 0), dt)
@@ -270,7 +273,7 @@ class UNetModel(ParamTree):
             return b
 
         emb_w, emb_b, off = [], [], 0
-        kv_text, kv_img, kv_off = [], [], 0
+        k_text, k_img, kv_off = [], [], 0
         for L in self.all_layers():
             p, e = L.prefix, {}
             if L.kind == "conv_in":
@@ -296,18 +299,20 @@ class UNetModel(ParamTree):
                 e["blk"] = block(p + ".transformer_blocks.0", cross=L.kind == "spatial")
                 if L.kind == "spatial":
                     a = p + ".transformer_blocks.0.attn2"
-                    kv_text += [sd[a + ".to_k.weight"], sd[a + ".to_v.weight"]]
+                    k_text.append(sd[a + ".to_k.weight"])
+                    e["wv_text"] = pack.pack_linear(sd[a + ".to_v.weight"], dt)
                     if self.cfg["image_cross_attention"]:
-                        kv_img += [sd[a + ".to_k_ip.weight"], sd[a + ".to_v_ip.weight"]]
-                    e["kv"] = (kv_off, L.inner); kv_off += 2 * L.inner
+                        k_img.append(sd[a + ".to_k_ip.weight"])
+                        e["wv_img"] = pack.pack_linear(sd[a + ".to_v_ip.weight"], dt)
+                    e["kv"] = (kv_off, L.inner); kv_off += L.inner
             elif L.kind == "down":
                 e["w"], e["b"] = pack.pack_conv2d(sd[p + ".op.weight"], dt), f32(p + ".op.bias")
             elif L.kind == "up":
                 e["w"], e["b"] = pack.pack_conv2d(sd[p + ".conv.weight"], dt), f32(p + ".conv.bias")
             P[p] = e
         P["emb_w"], P["emb_b"] = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
-        P["kv_text"] = pack.pack_linear(torch.cat(kv_text, 0), dt)
-        P["kv_img"] = pack.pack_linear(torch.cat(kv_img, 0), dt) if kv_img else None
+        P["k_text"] = pack.pack_linear(torch.cat(k_text, 0), dt)
+        P["k_img"] = pack.pack_linear(torch.cat(k_img, 0), dt) if k_img else None
         P["time"] = [f32("time_embed.0.weight"), f32("time_embed.0.bias"), f32("time_embed.2.weight"), f32("time_embed.2.bias")]
         if self.fs_condition:
             P["fps"] = [f32("fps_embedding.0.weight"), f32("fps_embedding.0.bias"), f32("fps_embedding.2.weight"), f32("fps_embedding.2.bias")]
@@ -332,11 +337,22 @@ class UNetModel(ParamTree):
         ctx = context.to(dt)
         text = ctx[:, :77].reshape(B * 77, -1).contiguous()
         img = ctx[:, 77:].reshape(B * T * 16, -1).contiguous()
-        kv_t = ops.linear(text, P["kv_text"])
-        kv_i = ops.linear(img, P["kv_img"]) if P["kv_img"] is not None else None
+        k_t = ops.linear(text, P["k_text"])                                   # every layer's text keys: [B*77, sum C]
+        k_i = ops.linear(img, P["k_img"]) if P["k_img"] is not None else None
+        vt_t, vt_i = {}, {}
+        for L in self.all_layers():                                            # values, transposed per layer (V^T rows = channels)
+            if L.kind != "spatial":
+                continue
+            e = P[L.prefix]
+            v = torch.zeros((B, L.inner, 80), device=ctx.device, dtype=dt)     # 77 keys padded to a 16-byte multiple
+            for b in range(B):
+                ops.linear_t(e["wv_text"], text[b * 77:(b + 1) * 77], out=v[b])
+            vt_t[L.prefix] = v
+            if k_i is not None:
+                vt_i[L.prefix] = ops.linear_t(e["wv_img"], img)                # [C, B*T*16], frame f at columns 16f..
         if len(self._ctx_cache) >= 4:
             self._ctx_cache.pop(next(iter(self._ctx_cache)))
-        self._ctx_cache[key] = (kv_t, kv_i, context)  # keep `context` alive so data_ptr stays unique
+        self._ctx_cache[key] = (k_t, k_i, vt_t, vt_i, context)  # keep `context` alive so data_ptr stays unique
         return self._ctx_cache[key]
 
     # ---- layer executors (all enqueue HIP kernels; tensors are token matrices [(b t) hw, C]) -------------
@@ -365,15 +381,17 @@ class UNetModel(ParamTree):
         F_, N, C_, heads = B * T, H * W, L.inner, L.heads
         blk = e["blk"]
         x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=N, eps=1e-6), *e["in"])
-        qkv = ops.linear(ops.layernorm(x, *blk["norm1"]), blk["attn1.qkv"])
-        att = ops.attention(qkv[:, :C_], [(qkv[:, C_:2 * C_], qkv[:, 2 * C_:], N, 1)], B=F_, H=heads, Nq=N, scale=0.125)
+        n1 = ops.layernorm(x, *blk["norm1"])
+        qk = ops.linear(n1, blk["attn1.qk"])
+        vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
+        att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125)
         x = ops.linear(att, *blk["attn1.o"], residual=x)
         q = ops.linear(ops.layernorm(x, *blk["norm2"]), blk["attn2.q"])
-        kv_t, kv_i, _ = kv
+        k_t, k_i, vt_t, vt_i, _ = kv
         off, _ = e["kv"]
-        sets = [(kv_t[:, off:off + C_], kv_t[:, off + C_:off + 2 * C_], 77, T)]
-        if kv_i is not None:
-            sets.append((kv_i[:, off:off + C_], kv_i[:, off + C_:off + 2 * C_], 16, 1))
+        sets = [(k_t[:, off:off + C_], vt_t[L.prefix].reshape(-1, 80), 77, T, C_ * 80)]
+        if k_i is not None:
+            sets.append((k_i[:, off:off + C_], vt_i[L.prefix], 16, 1, 16))
         att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
         x = self._ff(blk, x)

@@ -85,13 +85,16 @@ int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, i
                        void* stream);
 
 /* Fused multi-head attention, d_head = 64, no mask, up to two key/value sets with independent softmaxes whose
- * outputs are summed. q rows: b*Nq + i, head h at columns [64h, 64h+64). K/V rows of set s: (b / kv_div[s])*Nk[s] + j.
+ * outputs are summed. q rows: b*Nq + i, head h at columns [64h, 64h+64). K rows of set s: (b / kv_div[s])*Nk[s] + j.
+ * V is passed TRANSPOSED: vt[s] + (b / kv_div[s]) * vt_bs[s] + (64h + d) * ldvt[s] + j  (row = channel, column = key;
+ * the row must be readable — zero or finite — up to the next multiple of 16 bytes past Nk). `zeros`: >= 16 zero bytes.
  * replaces CrossAttention.forward / efficient_forward = xformers.ops.memory_efficient_attention
  * (attention.py:81-144, 146-209). */
 typedef struct geo4d_attention_t {
     const void* q; void* o;
-    const void* k[2]; const void* v[2];
-    long ldq, ldo, ldk[2], ldv[2];
+    const void* k[2]; const void* vt[2];
+    const void* zeros;
+    long ldq, ldo, ldk[2], ldvt[2], vt_bs[2];
     int Nk[2], kv_div[2];
     int B, H, Nq, nseg, head_dim, dtype;
     float scale;

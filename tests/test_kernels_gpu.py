@@ -184,17 +184,39 @@ def _sdpa(q, k, v, scale):
     return torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v
 
 
+def _vt(v, b, n, pad=None):
+    """[b*n, C] row-major values -> V^T [C, b*n] (+ zero padded columns), the layout geo4d_attention consumes."""
+    t = v.t().contiguous()
+    if pad:
+        t = torch.nn.functional.pad(t, (0, pad - t.shape[1]))
+    return t.contiguous()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N", [40, 160, 200])
+@pytest.mark.parametrize("N", [40, 160, 200, 2560])
 def test_attention_self(dev, dtype, N):
     from geo4d_amd import ops
-    B, H = 3, 5
-    qkv = rnd((B * N, 3 * H * 64), dev, dtype, 30)
+    B, H = (3, 5) if N < 1000 else (1, 2)
     C_ = H * 64
-    out = ops.attention(qkv[:, :C_], [(qkv[:, C_:2 * C_], qkv[:, 2 * C_:], N, 1)], B=B, H=H, Nq=N, scale=0.125)
+    qkv = rnd((B * N, 3 * C_), dev, dtype, 30)
+    vt = _vt(qkv[:, 2 * C_:], B, N)
+    out = ops.attention(qkv[:, :C_], [(qkv[:, C_:2 * C_], vt, N, 1, N)], B=B, H=H, Nq=N, scale=0.125)
     f = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     ref = _sdpa(f[0], f[1], f[2], 0.125).permute(0, 2, 1, 3).reshape(B * N, C_)
     check(f"attn self N={N}", out, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_v_projected_transposed(dev, dtype):
+    """linear_t writes V^T directly (operand-swapped GEMM): same numbers as projecting then transposing."""
+    from geo4d_amd import ops
+    M, K, N = 200, 128, 192
+    x, w = rnd((M, K), dev, dtype, 60), rnd((N, K), dev, dtype, 61, 0.1)
+    vt = ops.linear_t(w, x)
+    check("linear_t", vt, (x.float() @ w.float().t()).t(), dtype)
+    vt2 = ops.linear_t(w, x[:77], pad_cols=80)
+    assert vt2.shape == (N, 80) and vt2[:, 77:].abs().max().item() == 0
+    check("linear_t padded", vt2[:, :77], (x[:77].float() @ w.float().t()).t(), dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -206,7 +228,9 @@ def test_attention_cross_two_sets(dev, dtype):
     q = rnd((Bs * T * N, C_), dev, dtype, 31)
     kt, vt = rnd((Bs * 77, C_), dev, dtype, 32), rnd((Bs * 77, C_), dev, dtype, 33)
     ki, vi = rnd((Bs * T * 16, C_), dev, dtype, 34), rnd((Bs * T * 16, C_), dev, dtype, 35)
-    out = ops.attention(q, [(kt, vt, 77, T), (ki, vi, 16, 1)], B=Bs * T, H=H, Nq=N, scale=0.125)
+    vt_text = torch.stack([_vt(vt[b * 77:(b + 1) * 77], 1, 77, pad=80) for b in range(Bs)])      # [Bs, C, 80]
+    vt_img = _vt(vi, Bs * T, 16)                                                                  # [C, Bs*T*16]
+    out = ops.attention(q, [(kt, vt_text.reshape(-1, 80), 77, T, C_ * 80), (ki, vt_img, 16, 1, 16)], B=Bs * T, H=H, Nq=N, scale=0.125)
 
     def heads(x, b, n):
         return x.float().reshape(b, n, H, 64).permute(0, 2, 1, 3)
@@ -224,7 +248,7 @@ def test_attention_online_softmax_rescale(dev, dtype):
     N, H = 256, 1
     q, k, v = rnd((N, 64), dev, dtype, 36), rnd((N, 64), dev, dtype, 37), rnd((N, 64), dev, dtype, 38)
     k[200] = (q[7].float() * 4).to(dtype)
-    out = ops.attention(q, [(k, v, N, 1)], B=1, H=H, Nq=N, scale=0.125)
+    out = ops.attention(q, [(k, _vt(v, 1, N), N, 1, N)], B=1, H=H, Nq=N, scale=0.125)
     check("attn spike", out, _sdpa(q.float(), k.float(), v.float(), 0.125), dtype, scale=2.0)
 
 
