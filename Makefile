@@ -4,7 +4,9 @@ ARCH  ?= gfx950
 SRC   := $(wildcard geo4d_amd/csrc/*.hip)
 OBJ   := $(patsubst geo4d_amd/csrc/%.hip,build/%.o,$(SRC))
 LIB   := geo4d_amd/csrc/libgeo4d_hip.so
-CXXFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Igeo4d_amd/csrc -Wall -Wno-unused-function
+# -amdgpu-mfma-vgpr-form: gfx950 has a unified register file; keeping MFMA C/D in VGPRs removes the v_accvgpr_read/write
+# traffic between the matrix pipe and the softmax / epilogue VALU code (attention loop 665 -> 551 instructions per tile).
+CXXFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Igeo4d_amd/csrc -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form
 
 all: $(LIB)
 

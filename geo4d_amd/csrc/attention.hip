@@ -25,7 +25,7 @@ namespace {
 // K tiles are [64 keys][64 d] and V^T tiles [64 d][64 keys]: both are 64 rows of 16-byte slots filled by LDS-DMA
 // (lane-linear image), XOR-swizzled on the source side (128-byte rows: slot = chunk ^ ((row >> 1) & 7) as in gemm.hip;
 // 256-byte f32 rows: slot = chunk ^ (row & 15)).
-template <typename T>
+template <typename T, int NSEG>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = (int)sizeof(T);
@@ -55,13 +55,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
             qf[kk] = v;
         }
     }
-    f32x16 of[2], oa[2];
+    f32x16 of[NSEG == 1 ? 1 : 2], oa[2];        // `of` (sum over segments) only exists for the dual-KV cross attention
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { of[d][r] = 0.f; oa[d][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) {
+            oa[d][r] = 0.f;
+            if constexpr (NSEG > 1) of[d][r] = 0.f;
+        }
     float m_run = -INFINITY, l_run = 0.f;       // running max of RAW scores; sums of exp2((s - m) * c)
     const float c2 = p.scale * 1.4426950408889634f;
+    // lazy rescale (defer-max): the running max is only raised when some row's tile max exceeds it by more than THR raw
+    // units, i.e. P = exp2((s - m) * c2) is allowed to reach 2^6 — exact in fp32, same relative precision in bf16/f16.
+    // Order: decide + rescale O and l BEFORE this tile's P is formed and after the previous tile's P.V completed.
+    const float thr = 6.0f / c2;
 
     // staging geometry of this lane: DMA instruction i of this wave covers rows (wave*NDMA + i)*RPI .. +RPI
     const int srow = lane / SLOTS, sslot = lane % SLOTS;
@@ -115,35 +122,38 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
             }
         }
         // ---- online softmax on raw scores; exp2 with the scale folded in ----------------------
-        float mt = -INFINITY;
+        if (tile * 64 + 64 > nk) {               // only a ragged last tile pays for masking (wave-uniform branch)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = tile * 64 + kb * 32 + acc_row(r, g);
-                const float sv = key < nk ? st[kb][r] : -INFINITY;
-                st[kb][r] = sv;
-                mt = fmaxf(mt, sv);
-            }
+                for (int r = 0; r < 16; ++r)
+                    if (tile * 64 + kb * 32 + acc_row(r, g) >= nk) st[kb][r] = -INFINITY;
+        }
+        float mt = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(st[0][r], st[1][r]));
         mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f((m_run - m_new) * c2);
-        const float mc = m_new * c2;
+        if (__any(mt > m_run + thr)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);   // m_run = -inf on the first tile -> 0
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oa[d][r] *= alpha;
+        }
+        const float mc = m_run * c2;
         float ls = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(fmaf(st[kb][r], c2, -mc));
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c2, -mc));   // raw v_exp_f32
                 st[kb][r] = e;
                 ls += e;
             }
-        l_run = l_run * alpha + ls;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oa[d][r] *= alpha;
+        l_run += ls;
         // ---- O^T += V^T.P^T -------------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -176,7 +186,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { of[d][r] += oa[d][r] * inv; oa[d][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (NSEG > 1) { of[d][r] += oa[d][r] * inv; oa[d][r] = 0.f; }
+                    else oa[d][r] *= inv;
+                }
             m_run = -INFINITY;
             l_run = 0.f;
         }
@@ -195,14 +208,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
                 if constexpr (ES == 2) {
                     float e[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { e[j] = of[d][4 * i + j]; e[4 + j] = 0.f; }
+                    for (int j = 0; j < 4; ++j) { e[j] = (NSEG > 1 ? of[d % (NSEG == 1 ? 1 : 2)] : oa[d])[4 * i + j]; e[4 + j] = 0.f; }
                     const u32x4 c = f32_to_chunk<T>(e);
                     u32x2 o2; o2[0] = c[0]; o2[1] = c[1];
                     *(u32x2*)(op + dcol) = o2;
                 } else {
                     float e[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) e[j] = of[d][4 * i + j];
+                    for (int j = 0; j < 4; ++j) e[j] = (NSEG > 1 ? of[d % (NSEG == 1 ? 1 : 2)] : oa[d])[4 * i + j];
                     *(u32x4*)(op + dcol) = f32_to_chunk<T>(e);
                 }
             }
@@ -331,10 +344,18 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     if (p.H > 65535 || p.B > 65535) { geo4d_set_error("attention: grid too large"); return GEO4D_EINVAL; }
     const dim3 grid((p.Nq + 127) / 128, p.H, p.B);
     hipStream_t st = (hipStream_t)stream;
-    switch (p.dtype) {
-        case GEO4D_F32: hipLaunchKernelGGL(flash_attn_kernel<float>, grid, dim3(256), 0, st, p); break;
-        case GEO4D_BF16: hipLaunchKernelGGL(flash_attn_kernel<bf16_t>, grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL(flash_attn_kernel<f16_t>, grid, dim3(256), 0, st, p); break;
+    if (p.nseg == 1) {
+        switch (p.dtype) {
+            case GEO4D_F32: hipLaunchKernelGGL((flash_attn_kernel<float, 1>), grid, dim3(256), 0, st, p); break;
+            case GEO4D_BF16: hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((flash_attn_kernel<f16_t, 1>), grid, dim3(256), 0, st, p); break;
+        }
+    } else {
+        switch (p.dtype) {
+            case GEO4D_F32: hipLaunchKernelGGL((flash_attn_kernel<float, 2>), grid, dim3(256), 0, st, p); break;
+            case GEO4D_BF16: hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 2>), grid, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((flash_attn_kernel<f16_t, 2>), grid, dim3(256), 0, st, p); break;
+        }
     }
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;

@@ -37,12 +37,19 @@ struct f16_t { unsigned short v; };
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
 }
-// round-to-nearest-even, NaN kept quiet
+// round-to-nearest-even in hardware: v_cvt_pk_bf16_f32 (gfx950) — one instruction per PAIR instead of ~5 VALU per element
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int f32x2_to_bf16x2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ unsigned int f32x2_to_f16x2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
+}
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
-    const unsigned int u = __float_as_uint(f);
-    const unsigned int r = u + 0x7fffu + ((u >> 16) & 1u);
-    const unsigned int q = u | 0x00400000u;  // quiet NaN, payload kept (select, not a branch)
-    return (unsigned short)((((u & 0x7fffffffu) > 0x7f800000u) ? q : r) >> 16);
+    return (unsigned short)(f32x2_to_bf16x2(f, 0.f) & 0xffffu);
 }
 __device__ __forceinline__ float f16_bits_to_f32(unsigned short b) {
     return (float)__builtin_bit_cast(_Float16, b);
@@ -101,15 +108,13 @@ template <> __device__ __forceinline__ u32x4 f32_to_chunk<float>(const float* in
 template <> __device__ __forceinline__ u32x4 f32_to_chunk<bf16_t>(const float* in) {
     u32x4 c;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        c[j] = (unsigned int)f32_to_bf16_bits(in[2 * j]) | ((unsigned int)f32_to_bf16_bits(in[2 * j + 1]) << 16);
+    for (int j = 0; j < 4; ++j) c[j] = f32x2_to_bf16x2(in[2 * j], in[2 * j + 1]);
     return c;
 }
 template <> __device__ __forceinline__ u32x4 f32_to_chunk<f16_t>(const float* in) {
     u32x4 c;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        c[j] = (unsigned int)f32_to_f16_bits(in[2 * j]) | ((unsigned int)f32_to_f16_bits(in[2 * j + 1]) << 16);
+    for (int j = 0; j < 4; ++j) c[j] = f32x2_to_f16x2(in[2 * j], in[2 * j + 1]);
     return c;
 }
 
