@@ -70,25 +70,44 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
     // Order: decide + rescale O and l BEFORE this tile's P is formed and after the previous tile's P.V completed.
     const float thr = 6.0f / c2;
 
-    // staging geometry of this lane: DMA instruction i of this wave covers rows (wave*NDMA + i)*RPI .. +RPI
+    // staging geometry of this lane: DMA instruction i of this wave covers rows (wave*NDMA + i)*RPI .. +RPI.
+    // Per-lane source pointers are resolved once per segment; a full tile then costs one 64-bit add per DMA.
     const int srow = lane / SLOTS, sslot = lane % SLOTS;
-    auto issue_tile = [&](int seg, int tile, int buf) {
+    const T* ksrc[NDMA];
+    const T* vsrc[NDMA];
+    int krow[NDMA], vkey[NDMA];
+    long kstep = 0;
+    auto setup_seg = [&](int seg) {
         const int nk = seg ? p.Nk[1] : p.Nk[0];
         const long ldk = seg ? p.ldk[1] : p.ldk[0], ldvt = seg ? p.ldvt[1] : p.ldvt[0];
         const long kvb = b / (seg ? p.kv_div[1] : p.kv_div[0]);
         const T* kp = (const T*)(seg ? p.k[1] : p.k[0]) + kvb * nk * ldk + h * 64;
         const T* vp = (const T*)(seg ? p.vt[1] : p.vt[0]) + kvb * (seg ? p.vt_bs[1] : p.vt_bs[0]) + (long)h * 64 * ldvt;
-        char* kb_ = lds + buf * 2 * TILE;
+        kstep = 64 * ldk;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const int row = (wave * NDMA + i) * RPI + srow;            // key index in tile / d index
             const int chunk = sslot ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15));   // logical 16-byte chunk fetched into this slot
-            const int key = tile * 64 + row;
-            const T* ks = key < nk ? kp + (long)key * ldk + chunk * EPC : Z;
+            krow[i] = row;
+            vkey[i] = chunk * EPC;                                      // first key of this lane's V^T chunk
+            ksrc[i] = kp + (long)row * ldk + chunk * EPC;
+            vsrc[i] = vp + (long)row * ldvt + chunk * EPC;
+        }
+    };
+    auto issue_tile = [&](int seg, int tile, int buf) {
+        const int nk = seg ? p.Nk[1] : p.Nk[0];
+        char* kb_ = lds + buf * 2 * TILE;
+        const bool full = tile * 64 + 64 <= nk;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const T* ks = ksrc[i] + (long)tile * kstep;
+            const T* vs = vsrc[i] + tile * 64;
+            if (!full) {
+                if (tile * 64 + krow[i] >= nk) ks = Z;
+                if (tile * 64 + vkey[i] >= nk) vs = Z;
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
                                              (__attribute__((address_space(3))) void*)(kb_ + (wave * NDMA + i) * 1024), 16, 0, 0);
-            const int key0 = tile * 64 + chunk * EPC;                   // first key of this V^T chunk (row = d)
-            const T* vs = key0 < nk ? vp + (long)row * ldvt + key0 : Z;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
                                              (__attribute__((address_space(3))) void*)(kb_ + TILE + (wave * NDMA + i) * 1024), 16, 0, 0);
         }
@@ -97,6 +116,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
     // swizzled fragment offsets (row li of a 32-row block; (li >> 1) & (SLOTS-1) is block independent)
     const int swz = ES == 2 ? ((li >> 1) & 7) : (li & 15);   // 128-byte rows: 2 rows per bank row; 256-byte rows: 1
     int seg = 0, tile = 0, buf = 0;
+    setup_seg(0);
     issue_tile(0, 0, 0);
     while (true) {
         __syncthreads();                         // DMA of this tile landed (vmcnt(0)); everyone finished the previous tile
@@ -105,7 +125,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
         int nseg2 = seg, ntile2 = tile + 1;
         if (ntile2 >= ntile) { nseg2 = seg + 1; ntile2 = 0; }
         const bool has_next = nseg2 < p.nseg;
-        if (has_next) issue_tile(nseg2, ntile2, buf ^ 1);      // flies while this tile is consumed
+        if (has_next) {
+            if (nseg2 != seg) setup_seg(nseg2);
+            issue_tile(nseg2, ntile2, buf ^ 1);                // flies while this tile is consumed
+        }
         const char* ktile = lds + buf * 2 * TILE;
         const char* vtile = ktile + TILE;
 
@@ -129,9 +152,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
                 for (int r = 0; r < 16; ++r)
                     if (tile * 64 + kb * 32 + acc_row(r, g) >= nk) st[kb][r] = -INFINITY;
         }
-        float mt = fmaxf(st[0][0], st[1][0]);
+        float mt = st[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(st[0][r], st[1][r]));
+        for (int r = 1; r < 16; r += 2)          // v_max3_f32: 2 new values per instruction, no canonicalising v_max pairs
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[0][r]), "v"(st[0][r + 1 < 16 ? r + 1 : r]));
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[1][r]), "v"(st[1][r + 1]));
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         if (__any(mt > m_run + thr)) {
             const float m_new = fmaxf(m_run, mt);
@@ -143,16 +170,22 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oa[d][r] *= alpha;
         }
-        const float mc = m_run * c2;
-        float ls = 0.f;
+        const f32x2 c2v = {c2, c2};
+        const f32x2 mcv = {-m_run * c2, -m_run * c2};
+        f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c2, -mc));   // raw v_exp_f32
-                st[kb][r] = e;
-                ls += e;
+            for (int r = 0; r < 16; r += 2) {     // v_pk_fma_f32 + 2 x raw v_exp_f32 + v_pk_add_f32 per pair
+                f32x2 x = {st[kb][r], st[kb][r + 1]};
+                x = __builtin_elementwise_fma(x, c2v, mcv);
+                x[0] = __builtin_amdgcn_exp2f(x[0]);
+                x[1] = __builtin_amdgcn_exp2f(x[1]);
+                st[kb][r] = x[0];
+                st[kb][r + 1] = x[1];
+                ls2 += x;
             }
+        const float ls = ls2[0] + ls2[1];
         l_run += ls;
         // ---- O^T += V^T.P^T -------------------------------------------------------------------
 #pragma unroll
