@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
     setup_seg(0);
     issue_tile(0, 0, 0);
     while (true) {
-        __syncthreads();                         // DMA of this tile landed (vmcnt(0)); everyone finished the previous tile
+        // LDS-DMA is invisible to hipcc's waitcnt insertion inside the loop: drain it explicitly, THEN barrier
+        // (without the explicit wait the barrier can release while this tile is still in flight -> stale LDS reads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // this tile landed for every wave; everyone finished the previous tile
         const int nk = seg ? p.Nk[1] : p.Nk[0];
         const int ntile = (nk + 63) >> 6;
         int nseg2 = seg, ntile2 = tile + 1;

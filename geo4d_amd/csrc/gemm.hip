@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
             fetch_pix();
             issue_slab(0);
         }
-        __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA must be drained explicitly before the barrier
+        __syncthreads();
         for (int s = 0; s < nslab; ++s) {
             const int buf = s & 1;
             if (s + 1 < nslab && !(p.debug_ablate & 1)) issue_slab(buf ^ 1);
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
 #pragma unroll
                     for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fb[b], fa[a]);   // C rows = n, C cols = m
             }
-            __syncthreads();   // next stage landed (vmcnt(0)) and every wave is done reading this one
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (explicit: never rely on hipcc for DMA)
+            __syncthreads();                                    // ... for every wave, and everyone is done reading this one
         }
     } else {
         // 3-deep ring, DMA two stages ahead, ONE barrier per stage, counted vmcnt (never 0 in the steady state):
