@@ -51,7 +51,7 @@ __device__ __forceinline__ float load_res(const void* R, long idx, int dt) {
 template <int BM, int BN, int WM, int WN, int ST>
 constexpr int stage_bytes() {
     constexpr int ring = ST * (BM + BN) * PITCH;
-    constexpr int epi = 4 * (BM / WM) * (BN / WN + 4) * 4;   // fp32 transpose tiles of the 4 waves
+    constexpr int epi = WM * WN * (BM / WM) * (BN / WN + 4) * 4;   // fp32 transpose tiles of all waves
     return ring > epi ? ring : epi;
 }
 template <int BM, int BN, int WM, int WN, int ST>
@@ -60,14 +60,16 @@ constexpr int smem_bytes() {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int ST>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_conv_gemm_t p) {
+    constexpr int NT = WM * WN * 64;              // 256 threads (4 waves) or 512 (8 waves: one 256x128 tile per CU)
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = BKC * EPC;
     constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
-    constexpr int ACH = BM * BKC / 256, BCH = BN * BKC / 256;
+    constexpr int ACH = BM * BKC / NT, BCH = BN * BKC / NT;
+    constexpr int RSTEP = NT / 8;                 // rows covered by one staging pass of the whole workgroup
     constexpr int WTM = MB * 32, WTN = NB * 32;   // wave tile
     constexpr int SP = WTN + 4;                   // fp32 staging pitch (floats)
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
     static_assert(MB >= 1 && NB >= 1 && ACH >= 1 && BCH >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* rowpix = (int*)(smem + stage_bytes<BM, BN, WM, WN, ST>());
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
     {
         const int hlim = p.ups == 2 ? 2 * p.Hin : p.Hin, wlim = p.ups == 2 ? 2 * p.Win : p.Win;
         const int ush = p.ups == 2 ? 1 : 0;
-        for (int e = tid; e < BM * ntap; e += 256) {
+        for (int e = tid; e < BM * ntap; e += NT) {
             const int row = e / ntap, tap = e - row * ntap;
             const int m = tm * BM + row;
             int pix = -1;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
     const T* wptr[BCH];
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-        const int n = tn * BN + r0 + i * 32;
+        const int n = tn * BN + r0 + i * RSTEP;
         wptr[i] = n < p.N ? W + (long)n * p.ldw + csrc : nullptr;
     }
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
     long k0 = (long)s_begin * BK;
     auto fetch_pix = [&]() {
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) pix[i] = rowpix[(r0 + i * 32) * ntap + tap];
+        for (int i = 0; i < ACH; ++i) pix[i] = rowpix[(r0 + i * RSTEP) * ntap + tap];
     };
     // one LDS-DMA per 8 rows: wave-uniform destination (M0) + lane * 16 B
     auto issue_slab = [&](int buf) {
@@ -144,13 +146,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const geo4d_conv_gemm_t 
         for (int i = 0; i < ACH; ++i) {
             const T* src = pix[i] >= 0 ? A + (long)pix[i] * p.lda + c0 + csrc : Z;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + i * 32 * PITCH), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + i * RSTEP * PITCH), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const T* src = wptr[i] ? wptr[i] + k0 : Z;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + (BM + i * 32) * PITCH), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + (BM + i * RSTEP) * PITCH), 16, 0, 0);
         }
         k0 += BK;
         c0 += BK;
@@ -440,7 +442,7 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     }
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid((unsigned)tiles, (unsigned)p.batch, (unsigned)splits);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, p);
     GEO4D_CHECK_LAUNCH();
     if (splits > 1) {
         const long total = (long)p.batch * p.M * (p.N / 8);
@@ -458,6 +460,18 @@ struct TileCfg { int bm, bn; float eff; };
 template <typename T>
 int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     static const TileCfg cfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.80f}, {64, 64, 0.62f}, {128, 32, 0.50f}};
+    if (p.tile_hint == 11) {   // 8 waves, one 256x128 tile per CU: 0.75x the L2->LDS bytes and DMA issues per flop of 128x128
+        int sp = 1;
+        if (p.split_k > 1) {
+            if (!p.workspace || p.act == 2 || p.out_nchw || (p.N % 8) || (size_t)p.split_k * p.batch * p.M * p.N * 4 > p.workspace_bytes ||
+                p.K / (BKC * Elem<T>::EPC) / p.split_k < 1) {
+                geo4d_set_error("conv_gemm: split_k not applicable (workspace too small / epilogue not splittable)");
+                return GEO4D_EINVAL;
+            }
+            sp = p.split_k;
+        }
+        return launch_cfg<T, 256, 128, 4, 2, 2>(p, sp, stream);
+    }
     const int bk = BKC * Elem<T>::EPC;
     const int nslab = p.K / bk;
     const bool can_split = p.workspace && p.act != 2 && !p.out_nchw && (p.N % 8) == 0 && p.split_k != 1;

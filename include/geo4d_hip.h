@@ -53,7 +53,8 @@ typedef struct geo4d_conv_gemm_t {
     int out_dtype;       /* O/R element type                                            */
     int out_nchw;        /* 1: store O as [B][ldo][T][Hout*Wout] (ldo = channel count of the
                             destination tensor; O may point at a channel offset inside it) */
-    int tile_hint;       /* 0 auto, 1..5 force a tile shape (2-stage ring), 6..10 same, 3-stage */
+    int tile_hint;       /* 0 auto; 1..5 = 128x128, 128x64, 64x128, 64x64, 128x32 (4 waves, 2-stage ring);
+                            6..10 same tiles with a 3-stage ring; 11 = 256x128 with 8 waves */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
     int debug_ablate;    /* profiling only: bit0 skip steady-state DMA, bit1 skip MFMA  */
     float alpha;

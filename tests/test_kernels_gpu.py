@@ -34,7 +34,7 @@ def rnd(shape, dev, dtype, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_linear_bias_residual(dev, dtype, tile):
     from geo4d_amd import ops
     M, K, N = 300, 320, 200  # ragged M and N

@@ -99,7 +99,7 @@ def main():
         us = timeit()
         if args.explore:
             res = []
-            for tile in (1, 2, 3, 4, 6, 7, 8, 9):
+            for tile in (1, 2, 3, 4, 11):
                 for split in (1, 2, 4, 8):
                     try:
                         res.append((timeit(tile=tile, split=split), tile, split))
