@@ -152,6 +152,14 @@ def main():
             tflop_window *= (h * w * T) / (40 * 64 * 16)
         achieved = tflop_window * args.steps * world / dt / world      # per-GPU TFLOP/s
         peak = MFMA_PEAK_TF[args.dtype]
+        traffic, traffic_note = None, "no PMC summary committed for this dtype"
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if args.dtype == "bf16" and (args.height, args.width, T) == (320, 512, 16) and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)["per_unet_forward"]
+            traffic = (pmc["fetch_bytes_x2"] + pmc["write_bytes"]) * args.ddim_steps
+            traffic_note = ("L2-miss (fabric-side) bytes per window = 50 U-Net forwards x (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate "
+                            "rocprofv3 --pmc passes (profiles/r01_pmc_unet_forward.md; includes Infinity-Cache hits, decode not included)")
         res = {
             "metric": "denoised latent frames/sec (16x320x512, 50-step DDIM)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -164,7 +172,7 @@ def main():
                        "hipgraph": not args.no_graph},
             "split_ms_per_step": {"ddim_denoise": split[0] / args.steps, "vae_decode_4_modalities": split[1] / args.steps},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_note": traffic_note,
                          "note": f"whole step: {tflop_window:.1f} algorithmic TFLOP per window (SURVEY §8d: {TFLOP_UNET_STEP} x S + "
                                  f"{TFLOP_DECODE_FRAME} x T) / measured step time, per GPU; dominant kernel conv_gemm_kernel (MFMA implicit GEMM)"},
         }

@@ -130,37 +130,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     const int s_end = min(nslab_all, s_begin + per);
     const int nslab = s_end - s_begin;
 
+    // K order is channel-slab major, TAP MINOR: consecutive stages touch the same input rows shifted by one pixel / row /
+    // frame, so the re-reads of a 3x3 (or 3-tap temporal) gather hit the XCD's L2 instead of going back to Infinity Cache / HBM
+    // (tap-major order re-touched a line only after a full sweep over Cin: 42 GB of L2-miss traffic per U-Net forward).
     int pix[ACH];
-    const int slabs_per_tap = p.Cin / BK;
-    int tap = s_begin / slabs_per_tap;
-    int c0 = (s_begin - tap * slabs_per_tap) * BK;
-    long k0 = (long)s_begin * BK;
+    int tap = s_begin % ntap;
+    int c0 = (s_begin / ntap) * BK;
     auto fetch_pix = [&]() {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) pix[i] = rowpix[(r0 + i * RSTEP) * ntap + tap];
     };
-    // one LDS-DMA per 8 rows: wave-uniform destination (M0) + lane * 16 B
-    auto issue_slab = [&](int buf) {
+    // one LDS-DMA per 8 rows: wave-uniform destination (M0) + lane * 16 B. A stage = ACH + BCH pieces per wave, issued
+    // back-to-back at the top of the stage (A/B-tested against spreading them between the MFMA groups: 4-10 % slower).
+    constexpr int NP = ACH + BCH;
+    auto issue_piece = [&](int buf, int j) {
         char* base = smem + buf * (BM + BN) * PITCH + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const T* src = pix[i] >= 0 ? A + (long)pix[i] * p.lda + c0 + csrc : Z;
+        if (j < ACH) {
+            const T* src = pix[j] >= 0 ? A + (long)pix[j] * p.lda + c0 + csrc : Z;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + i * RSTEP * PITCH), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const T* src = wptr[i] ? wptr[i] + k0 : Z;
+                                             (__attribute__((address_space(3))) void*)(base + j * RSTEP * PITCH), 16, 0, 0);
+        } else {
+            const int i = j - ACH;
+            const T* src = wptr[i] ? wptr[i] + (long)tap * p.Cin + c0 : Z;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + (BM + i * RSTEP) * PITCH), 16, 0, 0);
         }
-        k0 += BK;
-        c0 += BK;
-        if (c0 >= p.Cin) {
-            c0 = 0;
-            ++tap;
-            if (tap < ntap) fetch_pix();
-        }
+    };
+    auto advance_cursor = [&]() {
+        if (++tap == ntap) { tap = 0; c0 += BK; }
+        if (ntap > 1 && c0 < p.Cin) fetch_pix();   // linear layers (1 tap) keep their row table entries in registers
+    };
+    auto issue_slab = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue_piece(buf, j);
+        advance_cursor();
     };
 
     f32x16 acc[MB][NB];
@@ -185,10 +188,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
         __syncthreads();
         for (int s = 0; s < nslab; ++s) {
             const int buf = s & 1;
-            if (s + 1 < nslab && !(p.debug_ablate & 1)) issue_slab(buf ^ 1);
+            if (s + 1 < nslab) issue_slab(buf ^ 1);   // all pieces up front: measured faster than spreading them over the MFMA groups
             const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
             const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
-            if (!(p.debug_ablate & 2))
 #pragma unroll
             for (int kk = 0; kk < BKC / 2; ++kk) {
                 u32x4 fa[MB], fb[NB];
