@@ -159,3 +159,47 @@ def test_window_end_to_end_vs_oracle(dev, mode, tol):
         po, pr = postprocess_window(out[:, 0]), opipe.postprocess_window(ref)
         flips = (po["valid"].cpu() != ~pr["invalid"]).float().mean().item()
         assert flips < 1e-3 and rel(po["inverse_depthmap"], pr["inverse_depthmap"]) < 1e-3
+
+
+def test_cfg_path_matches_reference_formula(dev):
+    """unconditional_guidance_scale != 1 (test_geo4d.py:171-188, ddim.py:218-231): two U-Net evaluations per step combined
+    as e_u + s (e_c - e_u) and rescaled by utils_diffusion.rescale_noise_cfg. Checked against the oracle restatement."""
+    from geo4d_amd.ddim import DDIMSampler
+    m, u, _ = _diffusion(dev, "f32")
+    gen = torch.Generator().manual_seed(99)
+    B, T, h, w = 1, 4, 8, 8
+    x_T = torch.randn((B, 16, T, h, w), generator=gen)
+    zc = torch.randn((B, 4, T, h, w), generator=gen)
+    ctx_c = torch.randn((B, 77 + 16 * T, u["unet_config"]["context_dim"]), generator=gen)
+    ctx_u = torch.randn((B, 77 + 16 * T, u["unet_config"]["context_dim"]), generator=gen)
+    cond = {"c_crossattn": [ctx_c.to(dev)], "c_concat": [zc.to(dev)]}
+    uc = {"c_crossattn": [ctx_u.to(dev)], "c_concat": [zc.to(dev)]}
+    out, _ = DDIMSampler(m).sample(S=3, conditioning=cond, batch_size=B, shape=[16, T, h, w], verbose=False, eta=0.0,
+                                   unconditional_guidance_scale=7.5, unconditional_conditioning=uc, fs=torch.tensor([24], device=dev),
+                                   x_T=x_T.to(dev), timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    usd = seeded_state_dict(u["shapes"])
+
+    def apply_model(x, t):
+        fs = torch.tensor([24])
+        e_c = ounet.unet_forward(usd, u["unet_config"], torch.cat([x, zc], 1), t, ctx_c, fs)
+        e_u = ounet.unet_forward(usd, u["unet_config"], torch.cat([x, zc], 1), t, ctx_u, fs)
+        o = e_u + 7.5 * (e_c - e_u)
+        dims = list(range(1, o.ndim))
+        resc = o * (e_c.std(dim=dims, keepdim=True) / o.std(dim=dims, keepdim=True))
+        return 0.7 * resc + 0.3 * o
+    ref = oddim.ddim_sample(apply_model, oddim.make_schedule(), oddim.make_scale_arr(), 3, x_T, eta=0.0)
+    e = rel(out, ref)
+    print(f"[cfg 7.5 + rescale 0.7] rel_l2 vs oracle = {e:.3e}")
+    assert e < 2e-4
+
+
+def test_stochastic_ddim_runs(dev):
+    """eta > 0 draws torch noise per step (no hipGraph); RNG streams differ from the CPU reference, so only sanity here."""
+    from geo4d_amd.ddim import DDIMSampler
+    m, u, _ = _diffusion(dev, "bf16")
+    B, T, h, w = 1, 4, 8, 8
+    cond = {"c_crossattn": [torch.randn((B, 77 + 16 * T, u["unet_config"]["context_dim"]), device=dev)],
+            "c_concat": [torch.randn((B, 4, T, h, w), device=dev)]}
+    out, _ = DDIMSampler(m).sample(S=3, conditioning=cond, batch_size=B, shape=[16, T, h, w], verbose=False, eta=1.0,
+                                   fs=torch.tensor([24], device=dev), timestep_spacing="uniform_trailing")
+    assert out.shape == (B, 16, T, h, w) and torch.isfinite(out).all()
