@@ -191,17 +191,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
             if (s + 1 < nslab) issue_slab(buf ^ 1);   // all pieces up front: measured faster than spreading them over the MFMA groups
             const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
             const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
+            // fragments are double-buffered in registers: the ds_reads of step kk+1 are in flight under the MFMAs of step kk
+            u32x4 fa[2][MB], fb[2][NB];
+#pragma unroll
+            for (int a = 0; a < MB; ++a) fa[0][a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[0]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fb[0][b] = *(const u32x4*)(bbase + b * 32 * PITCH + foff[0]);
 #pragma unroll
             for (int kk = 0; kk < BKC / 2; ++kk) {
-                u32x4 fa[MB], fb[NB];
+                if (kk + 1 < BKC / 2) {
 #pragma unroll
-                for (int a = 0; a < MB; ++a) fa[a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[kk]);
+                    for (int a = 0; a < MB; ++a) fa[(kk + 1) & 1][a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[kk + 1]);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) fb[b] = *(const u32x4*)(bbase + b * 32 * PITCH + foff[kk]);
+                    for (int b = 0; b < NB; ++b) fb[(kk + 1) & 1][b] = *(const u32x4*)(bbase + b * 32 * PITCH + foff[kk + 1]);
+                }
 #pragma unroll
                 for (int a = 0; a < MB; ++a)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fb[b], fa[a]);   // C rows = n, C cols = m
+                    for (int b = 0; b < NB; ++b) cmma<T>(acc[a][b], fb[kk & 1][b], fa[kk & 1][a]);   // C rows = n, C cols = m
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (explicit: never rely on hipcc for DMA)
             __syncthreads();                                    // ... for every wave, and everyone is done reading this one

@@ -16,6 +16,8 @@ import bench  # noqa: E402
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "gfx950.json")
     dev = torch.device("cuda:0")
+    old = dict(ops._tune_table())
+    ops._TUNE = {}                       # re-measure every shape this run touches; shapes it does not touch keep their entry
     for dtype in (sys.argv[2:] or ["bf16"]):
         model, pvae = bench.build(dtype, dev)
         T, h, w = 16, 40, 64
@@ -29,6 +31,10 @@ def main():
         decode_modalities(model, y, pvae)
         torch.cuda.synchronize()
         del model, pvae
+    fresh = dict(ops._TUNE)
+    changed = sum(1 for k, v in fresh.items() if old.get(k) != v)
+    ops._TUNE = {**old, **fresh}
+    print(f"re-measured {len(fresh)} shapes, {changed} changed")
     ops.save_tuning(out)
     print("saved", len(ops._tune_table()), "entries to", out)
 
