@@ -52,7 +52,7 @@ _WS = {}
 WORKSPACE_BYTES = 256 << 20
 
 # ---- per-shape launch tuning ------------------------------------------------------------------------------------
-# geo4d_conv_gemm has 5 tile shapes x split-K factors; the C-side heuristic is a fallback. The host keeps a table
+# geo4d_conv_gemm has 5 four-wave tile shapes + the 8-wave 256x128 / 256x256 tiles (hints 11, 13) x split-K factors; the C-side heuristic is a fallback. The host keeps a table
 # problem-signature -> (tile_hint, split_k): loaded from geo4d_amd/tuning/gfx950.json (measured on MI355X by
 # tools/tune_gemm.py) and, for shapes not in it, filled by timing the candidates on first eager use (never while a
 # hipGraph is being captured). Every candidate computes the same sums in the same k order per output element
@@ -62,7 +62,7 @@ import os as _os
 
 _TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950.json")
 _TUNE = None
-_CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
+_CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
 
 

@@ -54,7 +54,8 @@ typedef struct geo4d_conv_gemm_t {
     int out_nchw;        /* 1: store O as [B][ldo][T][Hout*Wout] (ldo = channel count of the
                             destination tensor; O may point at a channel offset inside it) */
     int tile_hint;       /* 0 auto; 1..5 = 128x128, 128x64, 64x128, 64x64, 128x32 (4 waves, 2-stage ring);
-                            6..10 same tiles with a 3-stage ring; 11 = 256x128 with 8 waves */
+                            8 waves, one tile per CU: 11 = 256x128, 13 = 256x256; deep-ring A/B variants:
+                            12 = 256x128 x 3 stages, 14 = 128x128 x 4 stages. Others: -EINVAL  */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
     int debug_ablate;    /* profiling only: bit0 skip steady-state DMA, bit1 skip MFMA  */
     float alpha;

@@ -34,7 +34,7 @@ def rnd(shape, dev, dtype, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14])
 def test_linear_bias_residual(dev, dtype, tile):
     from geo4d_amd import ops
     M, K, N = 300, 320, 200  # ragged M and N
@@ -83,6 +83,31 @@ def test_geglu(dev, dtype):
     ref = h[:, :inner] * TF.gelu(h[:, inner:])
     assert out.shape == (M, inner)
     check("geglu", out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [11, 12, 13, 14])
+def test_big_tiles_geglu_and_deep_conv(dev, dtype, tile):
+    """The 8-wave / deep-ring configurations (tile hints 11-15): GEGLU epilogue with 128-wide wave tiles, and a 3x3 conv
+    whose K loop (36 slabs in 16-bit) is longer than any ring, ragged M and N, with split-K 2 as well."""
+    from geo4d_amd import ops, pack
+    M, K, inner = 700, 256, 320
+    x = rnd((M, K), dev, dtype, 7)
+    w, b = rnd((2 * inner, K), dev, torch.float32, 8, 0.1), rnd((2 * inner,), dev, torch.float32, 9)
+    wp, bp = pack.pack_geglu(w, b, dtype)
+    out = ops.linear(x, wp, bp, act=2, tile_hint=tile)
+    h = x.float() @ w.to(dtype).float().t() + b
+    check(f"geglu tile{tile}", out, h[:, :inner] * TF.gelu(h[:, inner:]), dtype)
+    F, H, W, Ci, Co = 5, 12, 9, 256, 200
+    x_nchw = rnd((F, Ci, H, W), dev, dtype, 10)
+    wc = rnd((Co, Ci, 3, 3), dev, torch.float32, 11, 0.03)
+    bc = rnd((Co,), dev, torch.float32, 12)
+    xt = x_nchw.permute(0, 2, 3, 1).reshape(F * H * W, Ci).contiguous()
+    r = rnd((F * H * W, Co), dev, dtype, 14)
+    ref = TF.conv2d(x_nchw.float(), wc.to(dtype).float(), bc, padding=1).permute(0, 2, 3, 1).reshape(F * H * W, Co) + r.float()
+    for split in (1, 2):
+        o, _, _ = ops.conv2d(xt, pack.pack_conv2d(wc, dtype), bc, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=r, tile_hint=tile, split_k=split)
+        check(f"conv tile{tile} split{split}", o, ref, dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -352,6 +377,6 @@ def test_lds_dma_pipelines_are_race_free(dev, dtype):
     check("attn full-chip", first, ref, dtype, scale=2.0)
     M, K, Nn = 10240, 5760, 640
     x, w = rnd((M, 640), dev, dtype, 72), rnd((Nn, K), dev, dtype, 73, 0.02)
-    outs = [ops.conv2d(x, w, None, F=16, Hin=20, Win=32, KH=3, KW=3, pad=1, tile_hint=t)[0] for t in (1, 1, 1, 2, 3, 4)]
+    outs = [ops.conv2d(x, w, None, F=16, Hin=20, Win=32, KH=3, KW=3, pad=1, tile_hint=t, split_k=1)[0] for t in (1, 1, 1, 2, 3, 4, 11, 12, 12, 13, 13, 14, 14)]   # same split => same fp32 association
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "conv_gemm output depends on launch / tile shape"

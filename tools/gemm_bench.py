@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--filter", default="")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--vendor", action="store_true", help="also time the vendor library on the same shape (hipBLASLt via F.linear, MIOpen via F.conv2d channels_last): a calibration point, never used by the product path")
     ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
@@ -97,9 +98,30 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / args.iters
         us = timeit()
+        vend = None
+        if args.vendor:
+            import torch.nn.functional as Fn
+            if kind == "c3":
+                xi = x.view(F_, H, W, Cin).permute(0, 3, 1, 2)     # channels_last view
+                wi = w.view(N, 3, 3, Cin).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+                vfn = lambda: Fn.conv2d(xi, wi, b.to(dt), padding=1)
+            elif kind == "t3":
+                vfn = None
+            else:
+                vfn = lambda: Fn.linear(x, w, b.to(dt))
+            if vfn is not None:
+                for _ in range(3):
+                    vfn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    vfn()
+                e1.record()
+                torch.cuda.synchronize()
+                vend = e0.elapsed_time(e1) * 1e3 / args.iters
         if args.explore:
             res = []
-            for tile in (1, 2, 3, 4, 11):
+            for tile in (1, 2, 3, 4, 11, 12, 13, 14):
                 for split in (1, 2, 4, 8):
                     try:
                         res.append((timeit(tile=tile, split=split), tile, split))
@@ -111,7 +133,7 @@ def main():
         tf = 2.0 * M * N * K / us / 1e6
         tot_ms += us * cnt / 1e3
         tot_tf += 2.0 * M * N * K * cnt / 1e12
-        print(f"{name:34s} {M:8d} {N:6d} {K:6d} {us:9.1f} {tf:8.1f}  x{cnt:3d} -> {us * cnt / 1e3:7.2f}")
+        print(f"{name:34s} {M:8d} {N:6d} {K:6d} {us:9.1f} {tf:8.1f}  x{cnt:3d} -> {us * cnt / 1e3:7.2f}" + (f"   vendor {vend:8.1f} us ({us / vend:4.2f}x ours/vendor)" if vend else ""))
     if tot_ms:
         print(f"U-Net GEMM census: {tot_tf:.2f} TFLOP in {tot_ms:.1f} ms = {tot_tf / tot_ms * 1e3:.0f} TF/s")
 
