@@ -76,6 +76,20 @@ def cpu_baseline(model, pvae, ddim_steps, T, h, w):
                       "decodes (attention's quadratic term ignored: favours the CPU)"}
 
 
+def gemm_timeline(model, x_T, cond, fs, dev):
+    """Dominant kernel, measured live: one EAGER U-Net forward (outside the timed region) with every geo4d_conv_gemm launch
+    bracketed by HIP events on the launch stream. Returns (launches, algorithmic TFLOP, total ms)."""
+    from geo4d_amd import ops
+    t = torch.tensor([499], device=dev)
+    model.apply_model(x_T, t, cond, fs=fs)
+    torch.cuda.synchronize()
+    ops.GEMM_TIMELINE = []
+    model.apply_model(x_T, t, cond, fs=fs)
+    torch.cuda.synchronize()
+    tl, ops.GEMM_TIMELINE = ops.GEMM_TIMELINE, None
+    return len(tl), sum(f for f, _, _ in tl) / 1e12, sum(a.elapsed_time(b) for _, a, b in tl)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,16 +164,19 @@ def main():
         tflop_window = TFLOP_UNET_STEP * args.ddim_steps + TFLOP_DECODE_FRAME * T
         if (args.height, args.width, T) != (320, 512, 16):
             tflop_window *= (h * w * T) / (40 * 64 * 16)
-        achieved = tflop_window * args.steps * world / dt / world      # per-GPU TFLOP/s
+        achieved = tflop_window * args.steps * world / dt / world      # per-GPU TFLOP/s, whole step
         peak = MFMA_PEAK_TF[args.dtype]
+        x_T = torch.randn((1, 16, T, h, w), generator=torch.Generator().manual_seed(7)).to(dev)
+        n_gemm, tf_gemm, ms_gemm = gemm_timeline(model, x_T, cond, fs, dev)
         traffic, traffic_note = None, "no PMC summary committed for this dtype"
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if args.dtype == "bf16" and (args.height, args.width, T) == (320, 512, 16) and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)["per_unet_forward"]
-            traffic = (pmc["fetch_bytes_x2"] + pmc["write_bytes"]) * args.ddim_steps
-            traffic_note = ("L2-miss (fabric-side) bytes per window = 50 U-Net forwards x (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate "
-                            "rocprofv3 --pmc passes (profiles/r01_pmc_unet_forward.md; includes Infinity-Cache hits, decode not included)")
+            traffic = pmc["fetch_bytes_x2"] + pmc["write_bytes"]
+            traffic_note = ("L2-miss (fabric-side) bytes of ONE U-Net forward, ALL its kernels (conv_gemm is ~80 % of them): "
+                            "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes (profiles/r01_pmc_unet_forward.md; "
+                            "Infinity-Cache hits included, so an upper bound on HBM bytes)")
         res = {
             "metric": "denoised latent frames/sec (16x320x512, 50-step DDIM)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,10 +188,17 @@ def main():
                        "parallelism": f"window-dp{world}" + (" + all-gather of decoded maps" if world > 1 else ""),
                        "hipgraph": not args.no_graph},
             "split_ms_per_step": {"ddim_denoise": split[0] / args.steps, "vae_decode_4_modalities": split[1] / args.steps},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (MFMA implicit GEMM: every conv / linear / batched GEMM of the path)",
+                         "achieved": tf_gemm / ms_gemm * 1e3, "peak": peak, "unit": "TFLOP/s", "frac": tf_gemm / ms_gemm * 1e3 / peak,
+                         "launches_per_unet_forward": n_gemm, "tflop_per_unet_forward": tf_gemm, "ms_per_unet_forward": ms_gemm,
+                         "avg_launch_us": 1e3 * ms_gemm / n_gemm,
                          "traffic": traffic, "traffic_note": traffic_note,
-                         "note": f"whole step: {tflop_window:.1f} algorithmic TFLOP per window (SURVEY §8d: {TFLOP_UNET_STEP} x S + "
-                                 f"{TFLOP_DECODE_FRAME} x T) / measured step time, per GPU; dominant kernel conv_gemm_kernel (MFMA implicit GEMM)"},
+                         "note": "sum of 2*M*N*K over the conv_gemm launches of ONE eager U-Net forward / sum of their HIP-event "
+                                 "durations on the launch stream (brackets include a split-K launch's reduce kernel and ~2 us of "
+                                 "dispatch gap each; the rocprofv3 kernel trace in profiles/ gives the pure kernel time)",
+                         "whole_step": {"achieved": achieved, "frac": achieved / peak,
+                                        "note": f"{tflop_window:.1f} algorithmic TFLOP per window (SURVEY §8d: {TFLOP_UNET_STEP} x S + "
+                                                f"{TFLOP_DECODE_FRAME} x T) / measured step time, per GPU"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, pvae, args.ddim_steps, T, h, w)

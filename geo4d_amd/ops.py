@@ -64,6 +64,7 @@ _TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning
 _TUNE = None
 _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
+GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
 
 
 def _tune_table():
@@ -149,6 +150,13 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
+    if GEMM_TIMELINE is not None:     # bench.py's per-launch HIP-event timeline of the dominant kernel (never on while capturing)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch(tile_hint, split_k)
+        e1.record()
+        GEMM_TIMELINE.append((2.0 * M * N * K * batch, e0, e1))
+        return out
     launch(tile_hint, split_k)
     return out
 
