@@ -122,14 +122,48 @@ class LatentDiffusion(nn.Module):
 
     # ---- conditioning front-end: N3 -----------------------------------------------------------------------------------
     def _n3(self, what):
-        raise NotImplementedError(f"{what}: the conditioning front-end (OpenCLIP text/image encoders, Resampler, VAE encode) is "
-                                  "SURVEY.md §8(f) N3 and is not built; pass precomputed `cond` tensors instead")
+        raise NotImplementedError(f"{what}: the OpenCLIP text/image encoders and the Resampler of the conditioning front-end are "
+                                  "SURVEY.md §8(f) N3 and are not built (VAE encode is); pass precomputed `cond` tensors instead")
 
     def get_learned_conditioning(self, c):
         self._n3("get_learned_conditioning")
 
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        """ddpm3d.py:674-681: sample the posterior (or pass a tensor through) and apply scale_factor."""
+        if isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        elif hasattr(encoder_posterior, "sample"):
+            z = encoder_posterior.sample(noise=noise)
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        return self.scale_factor * z
+
+    def _encode(self, fn, x):
+        reshape_back = self.encoder_type == "2d" and x.dim() == 5
+        if reshape_back:
+            b, c, t, h, w = x.shape
+            x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+        post = fn(x)                                   # all frames in one batch through the HIP encoder
+        if self.perframe_ae:
+            # the reference loops over frames and samples each posterior separately (ddpm3d.py:696-702): draw the noise
+            # frame by frame in that order so a seeded run consumes the CPU generator exactly as the reference does
+            noise = torch.cat([torch.randn((1,) + tuple(post.mean.shape[1:])) for _ in range(post.mean.shape[0])], 0)
+        else:
+            noise = None                               # one torch.randn of the whole batch (distributions.py:35-40)
+        z = self.get_first_stage_encoding(post, noise=noise).detach()
+        if reshape_back:
+            z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+        return z
+
+    @torch.no_grad()
     def encode_first_stage(self, x):
-        self._n3("encode_first_stage")
+        """ddpm3d.py:683-707: frames [b,3,t,H,W] (or [n,3,H,W]) in [-1,1] -> scale_factor * sampled latent [b,4,t,H/8,W/8]."""
+        return self._encode(self.first_stage_model.encode, x)
+
+    @torch.no_grad()
+    def encode_first_stage_adaptor(self, x):
+        """ddpm3d.py:775-798: the same through encoder_adaptor."""
+        return self._encode(self.first_stage_model.encode_with_adaptor, x)
 
     def embedder(self, x):
         self._n3("embedder")

@@ -173,15 +173,17 @@ def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, a
                      tile_hint=tile_hint, split_k=split_k)
 
 
-def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, ups=1, T=1, rowbias=None, rowbias_div=0,
+def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1, T=1, rowbias=None, rowbias_div=0,
            residual=None, act=0, out=None, out_dtype=None, out_nchw=False, nchw_channels=None, tile_hint=0, split_k=0):
     """x tokens [F*Hin*Win, Cin]; w packed [N, KH*KW*Cin]. Output tokens [F*Hout*Wout, N], or with out_nchw a
-    [B, C, T, Hout, Wout] tensor (`out` may be a channel-offset view of a wider tensor with `nchw_channels` channels)."""
+    [B, C, T, Hout, Wout] tensor (`out` may be a channel-offset view of a wider tensor with `nchw_channels` channels).
+    `pad_end` = extra zero rows / columns at the bottom / right only (ae_modules.py:102-106 pads (0,1,0,1) before its
+    stride-2 conv): the gather treats every out-of-image tap as zero, so only the output size changes."""
     Cin = x.shape[1]
     N = w.shape[0]
     Hs, Ws = Hin * ups, Win * ups
-    Hout = (Hs + 2 * pad - KH) // stride + 1
-    Wout = (Ws + 2 * pad - KW) // stride + 1
+    Hout = (Hs + 2 * pad + pad_end - KH) // stride + 1
+    Wout = (Ws + 2 * pad + pad_end - KW) // stride + 1
     M = F * Hout * Wout
     assert x.shape[0] == F * Hin * Win, (x.shape, F, Hin, Win)
     assert w.shape[1] == KH * KW * Cin, (w.shape, KH, KW, Cin)

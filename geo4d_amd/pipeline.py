@@ -66,6 +66,12 @@ def decode_modalities(model, samples, pointmap_vae=None):
 
 
 @torch.no_grad()
+def get_latent_z(model, videos):
+    """test_geo4d.py:110-115: videos [b,3,t,H,W] in [-1,1] -> z_video [b,4,t,H/8,W/8] (the c_concat conditioning)."""
+    return model.encode_first_stage(videos)
+
+
+@torch.no_grad()
 def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddim_steps=50, ddim_eta=1.,
                            unconditional_guidance_scale=1.0, cfg_img=None, fs=None, text_input=False,
                            multiple_cond_cfg=False, loop=False, interp=False, timestep_spacing='uniform',

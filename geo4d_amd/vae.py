@@ -9,12 +9,16 @@ with nearest-2x upsample convs, GroupNorm(32, eps 1e-6)+swish heads) and the con
 (autoencoder_adaptor.py:203-317) run as HIP kernels on channels-last tokens; all frames handed to one call are decoded
 as one batch (the reference's ``perframe_ae`` loop, ddpm3d.py:810-819, gives identical results frame by frame).
 
-The encode side (``encode`` / ``encoder_adaptor``) is SURVEY.md §8(f) N3 ("next"): its parameters are held for
-state_dict compatibility, calling it raises.
+The encode side — ``encode(x)`` (autoencoder.py:129-134) and ``encode_with_adaptor(x)`` (autoencoder.py:104-109), i.e.
+``Encoder.forward`` (ae_modules.py:537-580: conv_in, 4 levels of ResnetBlocks with stride-2 Downsample convs padded
+(0,1,0,1), mid ResnetBlock/AttnBlock/ResnetBlock, GroupNorm+swish+conv_out) followed by ``quant_conv`` — is the first
+piece of SURVEY.md §8(f) N3 (it produces the ``z_video`` conditioning of every window, test_geo4d.py:110-113,160). It runs on
+the same kernels; ``quant_conv`` (1x1) is folded into ``conv_out`` at pack time (W' = Wq·Wc, b' = Wq·bc + bq).
 """
 import torch
 
 from . import ops, pack
+from .posterior import DiagonalGaussianDistribution
 from .unet import ParamTree, init_params_, resolve_dtype
 
 
@@ -64,7 +68,7 @@ class AutoencoderKL(ParamTree):
         self.compute_dtype = resolve_dtype(compute_dtype)
         ch, mult, nres, zc = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"], dd["z_channels"]
         add = self.insert
-        # ---- encoder (held for strict state_dict loading only) --------------------------------------------
+        # ---- encoder (ae_modules.py:455-535) ------------------------------------------------------------------------
         add("encoder.conv_in.weight", (ch, dd["in_channels"], 3, 3)); add("encoder.conv_in.bias", (ch,))
         cin = ch
         for lvl, m in enumerate(mult):
@@ -182,6 +186,39 @@ class AutoencoderKL(ParamTree):
             P["adaptor"] = [resnet(f"decoder_adaptor.up.0.block.{b}") for b in range(nb)]
             P["adaptor_head"] = (norm("decoder_adaptor.norm_out"), pack.pack_conv2d(sd["decoder_adaptor.conv_out.weight"], dt),
                                  f32("decoder_adaptor.conv_out.bias"))
+        # ---- encoder (ae_modules.py:537-580) + quant_conv folded into conv_out -------------------------------------
+        ch, mult, nres = self.ddconfig["ch"], list(self.ddconfig["ch_mult"]), self.ddconfig["num_res_blocks"]
+        P["enc_in"] = (pack.pack_conv2d(sd["encoder.conv_in.weight"], dt, cin_pad=ka), f32("encoder.conv_in.bias"))
+        enc = []
+        for lvl in range(len(mult)):
+            for b in range(nres):
+                enc.append(("res", resnet(f"encoder.down.{lvl}.block.{b}")))
+            if lvl != len(mult) - 1:
+                q = f"encoder.down.{lvl}.downsample.conv"
+                enc.append(("down", (pack.pack_conv2d(sd[q + ".weight"], dt), f32(q + ".bias"))))
+        enc.append(("res", resnet("encoder.mid.block_1")))
+        p = "encoder.mid.attn_1"
+        enc.append(("attn", dict(norm=norm(p + ".norm"),
+                                 qk=(pack.pack_linear(torch.cat([sd[p + ".q.weight"], sd[p + ".k.weight"]], 0), dt),
+                                     torch.cat([sd[p + ".q.bias"], sd[p + ".k.bias"]]).float().contiguous()),
+                                 v=(pack.pack_linear(sd[p + ".v.weight"], dt), f32(p + ".v.bias")),
+                                 o=(pack.pack_linear(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias")))))
+        enc.append(("res", resnet("encoder.mid.block_2")))
+        P["enc"] = enc
+        wq2 = sd["quant_conv.weight"].float().reshape(2 * self.embed_dim, 2 * zc)
+        wfold = torch.einsum("om,mikl->oikl", wq2, sd["encoder.conv_out.weight"].float())
+        bfold = wq2 @ sd["encoder.conv_out.bias"].float() + sd["quant_conv.bias"].float()
+        P["enc_head"] = (norm("encoder.norm_out"), pack.pack_conv2d(wfold, dt), bfold.contiguous())
+        if self.adaptorconfig is not None:
+            ad = self.adaptorconfig
+            P["enc_adaptor_in"] = (pack.pack_conv2d(sd["encoder_adaptor.conv_in.weight"], dt, cin_pad=ka), f32("encoder_adaptor.conv_in.bias"))
+            P["enc_adaptor"] = [resnet(f"encoder_adaptor.down.0.block.{b}") for b in range(ad["num_res_blocks"])]
+            # conv_out -> in_channels (3), padded to one K slab so the result (+ x) feeds encoder.conv_in directly
+            wo = torch.zeros((ka,) + tuple(sd["encoder_adaptor.conv_out.weight"].shape[1:]), device=dev)
+            wo[: ad["in_channels"]] = sd["encoder_adaptor.conv_out.weight"]
+            bo = torch.zeros((ka,), device=dev)
+            bo[: ad["in_channels"]] = sd["encoder_adaptor.conv_out.bias"]
+            P["enc_adaptor_head"] = (norm("encoder_adaptor.norm_out"), pack.pack_conv2d(wo, dt), bo.contiguous())
         self._packed = P
         return P
 
@@ -265,11 +302,44 @@ class AutoencoderKL(ParamTree):
         self._head(P["adaptor_head"], self._conf(P, feat, n, H, W), n, H, W, out[:, c_rgb:], 1, c_rgb + c_conf)
         return out
 
-    def encode(self, x, **kwargs):
-        raise NotImplementedError("VAE encode is SURVEY.md §8(f) N3 (conditioning front-end), not built in this round; "
-                                  "pass precomputed latents (c_concat)")
+    def _moments(self, x, with_adaptor):
+        """x [n, in_channels, H, W] -> quant_conv(encoder(x)) as [n, 2*embed_dim, H/8, W/8] fp32."""
+        P = self._packed or self._pack()
+        n, ci, H, W = x.shape
+        nlev = len(self.ddconfig["ch_mult"])
+        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
+            raise ValueError(f"encode: H, W must be multiples of {1 << (nlev - 1)} (got {H}x{W})")
+        dt = self.compute_dtype
+        t = ops.tokens_from_ncthw(x.float().reshape(n, ci, 1, H, W).contiguous(), None, P["cpad"], dt)    # [n*H*W, cpad]
+        if with_adaptor:
+            if self.adaptorconfig is None:
+                raise RuntimeError("encode_with_adaptor needs adaptorconfig")
+            # VAEEncoderadaptor.forward (autoencoder_adaptor.py:166-199): conv_in, ResnetBlocks, norm+swish+conv_out, + x
+            h, _, _ = ops.conv2d(t, *P["enc_adaptor_in"], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1)
+            for e in P["enc_adaptor"]:
+                h = self._resnet(e, h, n, H, W)
+            gn, w, b = P["enc_adaptor_head"]
+            a = ops.groupnorm(h, *gn, F=n, HW=H * W, eps=1e-6, silu=True)
+            t, _, _ = ops.conv2d(a, w, b, F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=t)
+        h, _, _ = ops.conv2d(t, *P["enc_in"], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1)
+        for kind, e in P["enc"]:
+            if kind == "res":
+                h = self._resnet(e, h, n, H, W)
+            elif kind == "attn":
+                h = self._attn(e, h, n, H, W)
+            else:   # Downsample (ae_modules.py:90-109): zero-pad bottom / right by one, 3x3 stride-2 conv without padding
+                h, H, W = ops.conv2d(h, *e, F=n, Hin=H, Win=W, KH=3, KW=3, stride=2, pad=0, pad_end=1)
+        out = torch.empty((n, 2 * self.embed_dim, H, W), device=x.device, dtype=torch.float32)
+        self._head(P["enc_head"], h, n, H, W, out, 1, 2 * self.embed_dim)
+        return out
 
-    encode_with_adaptor = encode
+    @torch.no_grad()
+    def encode(self, x, **kwargs):
+        return DiagonalGaussianDistribution(self._moments(x, False))
+
+    @torch.no_grad()
+    def encode_with_adaptor(self, x, **kwargs):
+        return DiagonalGaussianDistribution(self._moments(x, True))
 
     def forward(self, *a, **k):
         raise NotImplementedError("training forward is out of scope; use decode / decode_with_conf_adaptor")

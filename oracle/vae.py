@@ -4,6 +4,9 @@ Follows lvdm/modules/networks/ae_modules.py (Decoder.forward :661-702, ResnetBlo
 AttnBlock.forward :53-78, Upsample.forward :123-127, Normalize :15-16 = GroupNorm(32, eps 1e-6), swish :10-12),
 lvdm/models/autoencoder_adaptor.py (VAEDecoderadaptor.forward :277-317) and lvdm/models/autoencoder.py
 (decode :136-139, decode_with_conf_adaptor :120-127). Operates on a reference-format AutoencoderKL state_dict.
+Encode side: Encoder.forward ae_modules.py:537-580, Downsample.forward :102-109,
+VAEEncoderadaptor.forward autoencoder_adaptor.py:166-199, AutoencoderKL.encode / encode_with_adaptor autoencoder.py:104-134;
+returns the posterior's `parameters` (mean | logvar), i.e. quant_conv(encoder(x)).
 """
 import torch
 import torch.nn.functional as F
@@ -74,3 +77,39 @@ def decode_with_conf_adaptor(sd, ddconfig, adaptorconfig, z):
     for blk in range(adaptorconfig["num_res_blocks"] + 1):
         h = _resnet(sd, h, f"decoder_adaptor.up.0.block.{blk}")
     return torch.cat([rgb, _head(sd, h, "decoder_adaptor")], dim=1)
+
+
+def encoder_forward(sd, ddconfig, x, prefix="encoder"):
+    nres, nlev = ddconfig["num_res_blocks"], len(ddconfig["ch_mult"])
+    h = _conv(sd, x, prefix + ".conv_in", 1)
+    for lvl in range(nlev):
+        for blk in range(nres):
+            h = _resnet(sd, h, f"{prefix}.down.{lvl}.block.{blk}")
+        if lvl != nlev - 1:
+            p = f"{prefix}.down.{lvl}.downsample.conv"
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[p + ".weight"], sd[p + ".bias"], stride=2)
+    h = _resnet(sd, h, prefix + ".mid.block_1")
+    h = _attn(sd, h, prefix + ".mid.attn_1")
+    h = _resnet(sd, h, prefix + ".mid.block_2")
+    return _head(sd, h, prefix)
+
+
+@torch.no_grad()
+def encode(sd, ddconfig, x):
+    """AutoencoderKL.encode(x).parameters: x [n,3,H,W] -> moments [n, 2*embed_dim, H/8, W/8]."""
+    return _conv(sd, encoder_forward(sd, ddconfig, x), "quant_conv", 0)
+
+
+@torch.no_grad()
+def encode_with_adaptor(sd, ddconfig, adaptorconfig, x):
+    h = _conv(sd, x, "encoder_adaptor.conv_in", 1)
+    for blk in range(adaptorconfig["num_res_blocks"]):
+        h = _resnet(sd, h, f"encoder_adaptor.down.0.block.{blk}")
+    x = x + _head(sd, h, "encoder_adaptor")
+    return _conv(sd, encoder_forward(sd, ddconfig, x), "quant_conv", 0)
+
+
+def first_stage_encoding(moments, scale_factor, noise):
+    """DiagonalGaussianDistribution.sample + get_first_stage_encoding (distributions.py:24-40, ddpm3d.py:674-681)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return scale_factor * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)

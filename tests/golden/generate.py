@@ -120,7 +120,30 @@ def script_functions(names):
     return ns
 
 
+def encode_fixtures():
+    """`python tests/golden/generate.py encode` -> vae_encode_tiny.pt: the reference AutoencoderKL.encode /
+    encode_with_adaptor moments and LatentDiffusion.encode_first_stage (seeded posterior sampling) on a tiny config."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    unet_cfg, dd, adp = tiny_configs()
+    model = build_reference(unet_cfg, dd, adp)
+    vae = model.first_stage_model
+    x = torch.rand((2, 3, 48, 64), generator=torch.Generator().manual_seed(310)) * 2 - 1
+    video = torch.rand((1, 3, 3, 48, 64), generator=torch.Generator().manual_seed(311)) * 2 - 1
+    with torch.no_grad():
+        mom = vae.encode(x).parameters
+        mom_a = vae.encode_with_adaptor(x).parameters
+        torch.manual_seed(4242)
+        z = model.encode_first_stage(video)          # perframe_ae=True: one CPU torch.randn per frame
+    print("encode", tuple(mom.shape), tuple(mom_a.shape), tuple(z.shape), float(mom.std()), float((mom_a - mom).abs().max()))
+    torch.save(dict(ddconfig=dd, adaptorconfig=adp, x=x, moments=mom, moments_adaptor=mom_a, video=video, seed=4242,
+                    scale_factor=model.scale_factor, perframe_ae=model.perframe_ae, z_first_stage=z,
+                    shapes={k: tuple(v.shape) for k, v in vae.state_dict().items()}), os.path.join(HERE, "vae_encode_tiny.pt"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "encode":
+        return encode_fixtures()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     from lvdm.models.samplers.ddim import DDIMSampler

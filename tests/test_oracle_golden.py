@@ -76,6 +76,51 @@ def test_vae_decode_matches_reference():
     assert rel(ray, d["decode_first_stage_4_8"]) < 2e-5
 
 
+def test_vae_encode_matches_reference():
+    """Oracle restatement of AutoencoderKL.encode / encode_with_adaptor and of the seeded posterior sampling inside
+    LatentDiffusion.encode_first_stage (perframe_ae=True: one CPU torch.randn per frame) vs reference-generated fixtures."""
+    g = load("vae_encode_tiny.pt")
+    sd = seeded_state_dict(g["shapes"])
+    m = ovae.encode(sd, g["ddconfig"], g["x"])
+    ma = ovae.encode_with_adaptor(sd, g["ddconfig"], g["adaptorconfig"], g["x"])
+    assert m.shape == g["moments"].shape
+    assert rel(m, g["moments"]) < 2e-5 and rel(ma, g["moments_adaptor"]) < 2e-5
+    v = g["video"]
+    b, c, t, h, w = v.shape
+    frames = v.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+    mom = ovae.encode(sd, g["ddconfig"], frames)
+    torch.manual_seed(g["seed"])
+    noise = torch.cat([torch.randn((1, 4) + tuple(mom.shape[2:])) for _ in range(b * t)], 0)
+    z = ovae.first_stage_encoding(mom, g["scale_factor"], noise)
+    z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+    assert rel(z, g["z_first_stage"]) < 2e-5
+
+
+def test_posterior_object_matches_reference_formulas():
+    """geo4d_amd.posterior.DiagonalGaussianDistribution vs the closed forms of lvdm/distributions.py:24-65 (CPU tensors:
+    the class is plumbing around the HIP-produced moments)."""
+    from geo4d_amd.posterior import DiagonalGaussianDistribution
+    g = torch.Generator().manual_seed(5)
+    mom = torch.randn((3, 8, 4, 5), generator=g) * 3
+    mom[0, 4:] = 40.0      # exercises the logvar clamp
+    p = DiagonalGaussianDistribution(mom)
+    mean, logvar = mom[:, :4], mom[:, 4:].clamp(-30.0, 20.0)
+    assert torch.equal(p.mean, mean) and torch.equal(p.logvar, logvar) and torch.equal(p.mode(), mean)
+    assert torch.allclose(p.std, torch.exp(0.5 * logvar)) and torch.allclose(p.var, torch.exp(logvar))
+    torch.manual_seed(9)
+    s = p.sample()
+    torch.manual_seed(9)
+    assert torch.allclose(s, mean + torch.exp(0.5 * logvar) * torch.randn(mean.shape))
+    n = torch.randn(mean.shape, generator=g)
+    assert torch.allclose(p.sample(noise=n), mean + p.std * n)
+    assert torch.allclose(p.kl(), 0.5 * torch.sum(mean ** 2 + p.var - 1.0 - logvar, dim=[1, 2, 3]))
+    q = DiagonalGaussianDistribution(torch.randn((3, 8, 4, 5), generator=g))
+    assert torch.allclose(p.kl(q), 0.5 * torch.sum((mean - q.mean) ** 2 / q.var + p.var / q.var - 1.0 - logvar + q.logvar, dim=[1, 2, 3]), rtol=1e-4)
+    assert torch.allclose(p.nll(n), 0.5 * torch.sum(np.log(2.0 * np.pi) + logvar + (n - mean) ** 2 / p.var, dim=[1, 2, 3]), rtol=1e-4)
+    d = DiagonalGaussianDistribution(mom, deterministic=True)
+    assert torch.equal(d.sample(), mean) and float(d.kl()) == 0.0
+
+
 def test_window_indices_bit_exact():
     g = load("glue.pt")
     for (T, stride), ref in g["windows"].items():

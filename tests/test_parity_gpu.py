@@ -86,6 +86,35 @@ def test_vae_decode_vs_reference_golden(dev, mode, tol):
     assert e1 < tol and e2 < tol
 
 
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_vae_encode_vs_reference_golden(dev, mode, tol):
+    """SURVEY §8(f) N3, first piece: AutoencoderKL.encode / encode_with_adaptor (Encoder + stride-2 Downsample with (0,1,0,1)
+    padding + mid attention + quant_conv folded into conv_out) vs moments produced by the reference itself."""
+    g = load("vae_encode_tiny.pt")
+    m = build_vae(g, dev, mode)
+    post = m.encode(g["x"].to(dev))
+    post_a = m.encode_with_adaptor(g["x"].to(dev))
+    e1, e2 = rel(post.parameters, g["moments"]), rel(post_a.parameters, g["moments_adaptor"])
+    print(f"[vae encode] mode={mode} encode {e1:.3e} encode_with_adaptor {e2:.3e} (tol {tol:.0e})")
+    assert post.parameters.shape == g["moments"].shape and post.mean.shape[1] == 4
+    assert e1 < tol and e2 < tol
+    with pytest.raises(ValueError):
+        m.encode(torch.zeros((1, 3, 20, 64), device=dev))     # 20 is not a multiple of 8
+
+
+def test_encode_first_stage_consumes_rng_like_reference(dev):
+    """LatentDiffusion.encode_first_stage (ddpm3d.py:683-707, test_geo4d.py:110-113): same seed -> same sampled z_video as the
+    reference (posterior noise is drawn on the CPU generator frame by frame because perframe_ae=True)."""
+    g = load("vae_encode_tiny.pt")
+    m, _, _ = _diffusion(dev, "f32")
+    from geo4d_amd.pipeline import get_latent_z
+    torch.manual_seed(g["seed"])
+    z = get_latent_z(m, g["video"].to(dev))
+    e = rel(z, g["z_first_stage"])
+    print(f"[encode_first_stage] rel_l2 vs reference = {e:.3e}")
+    assert z.shape == g["z_first_stage"].shape and e < 2e-4
+
+
 def _diffusion(dev, mode):
     from geo4d_amd.diffusion import LatentVisualDiffusion
     u, v = load("unet_tiny.pt"), load("vae_tiny.pt")
