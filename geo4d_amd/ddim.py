@@ -5,7 +5,8 @@ What changes is how a step is executed. The reference's ``p_sample_ddim`` (ddim.
 ``torch.full`` tensors and ~10 elementwise kernels per step on top of ~2000 eager launches of the U-Net. Here one step =
 [gather t from a device table] + [U-Net kernels] + [one fused DDIM-update kernel reading its coefficients from a device
 table indexed by a device-side step counter] + [counter -= 1]; nothing in it depends on host state, so the step is
-captured ONCE into a hipGraph and replayed S times (``use_graph=True``, default when eta == 0 and CFG scale == 1).
+captured ONCE into a hipGraph and replayed S times (``use_graph=True``, default when eta == 0; with classifier-free
+guidance the 2 (or 3, ``multicond``) U-Net evaluations and their combination are part of the captured step).
 """
 import numpy as np
 import torch
@@ -27,6 +28,8 @@ def make_ddim_timesteps(method, num_ddim, num_ddpm):
 
 
 class DDIMSampler(object):
+    multicond = False     # True in geo4d_amd.ddim_multiplecond.DDIMSampler (3-way guidance)
+
     def __init__(self, model, schedule="linear", use_graph=True, **kwargs):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
@@ -87,9 +90,17 @@ class DDIMSampler(object):
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         total = len(self.ddim_timesteps)
         kwargs.pop("clean_cond", None)
-        graph_ok = self.use_graph and eta == 0. and not cfg and callback is None and img_callback is None and total > 2
+        graph_ok = self.use_graph and eta == 0. and callback is None and img_callback is None and total > 2
+        # 3-way guidance of ddim_multiplecond.py:229-234 (image yes / text "" as a third evaluation)
+        uc_img = kwargs.get("unconditional_conditioning_img_nonetext") if (self.multicond and cfg) else None
+        if self.multicond and cfg and uc_img is None:
+            raise ValueError("DDIMSampler (multiple cond): unconditional_conditioning_img_nonetext is required when CFG is on")
+        cfg_img = kwargs.get("cfg_img")
+        cfg_img = unconditional_guidance_scale if cfg_img is None else cfg_img
         # static buffers: a captured step graph is reused across sample() calls with the same shapes / conditioning
-        cond_ptrs = tuple(t.data_ptr() for v in (conditioning or {}).values() for t in (v if isinstance(v, (list, tuple)) else [v]))
+        ptrs = lambda c: tuple(t.data_ptr() for v in (c or {}).values() for t in (v if isinstance(v, (list, tuple)) else [v])) if isinstance(c, dict) else ()
+        cond_ptrs = ptrs(conditioning) + ((ptrs(unconditional_conditioning), ptrs(uc_img), float(unconditional_guidance_scale),
+                                          float(cfg_img), float(guidance_rescale)) if cfg else ())
         key = (size, S, timestep_spacing, cond_ptrs, None if fs is None else fs.data_ptr(), tuple(sorted(kwargs)))
         cached = self._static if (graph_ok and self._graph_key == key) else None
         if cached is not None:
@@ -109,7 +120,11 @@ class DDIMSampler(object):
                 return self.model.apply_model(img, ts, conditioning, fs=fs, **kwargs)
             e_c = self.model.apply_model(img, ts, conditioning, fs=fs, **kwargs)
             e_u = self.model.apply_model(img, ts, unconditional_conditioning, fs=fs, **kwargs)
-            out = e_u + unconditional_guidance_scale * (e_c - e_u)
+            if uc_img is not None:
+                e_i = self.model.apply_model(img, ts, uc_img, fs=fs, **kwargs)
+                out = e_u + cfg_img * (e_i - e_u) + unconditional_guidance_scale * (e_c - e_i)
+            else:
+                out = e_u + unconditional_guidance_scale * (e_c - e_u)
             if guidance_rescale > 0.0:                                          # utils_diffusion.py:147-158
                 dims = list(range(1, out.ndim))
                 resc = out * (e_c.std(dim=dims, keepdim=True) / out.std(dim=dims, keepdim=True))
@@ -137,7 +152,7 @@ class DDIMSampler(object):
             for _ in range(total - 1):
                 g.replay()
             self._static, self._graph_key = (g, img, ts, idx, pred_x0), key
-            self._keepalive = (conditioning, fs)     # keeps the captured device pointers valid and unique
+            self._keepalive = (conditioning, unconditional_conditioning, uc_img, fs)   # keeps the captured device pointers valid and unique
         else:
             for i in range(total):
                 noise = None

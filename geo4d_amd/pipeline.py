@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from .ddim import DDIMSampler
+from .ddim_multiplecond import DDIMSampler as DDIMSamplerMulticond
 
 
 def window_slices(T, stride=4, length=16):
@@ -76,22 +77,29 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
                            unconditional_guidance_scale=1.0, cfg_img=None, fs=None, text_input=False,
                            multiple_cond_cfg=False, loop=False, interp=False, timestep_spacing='uniform',
                            guidance_rescale=0.0, pointmap_vae=None, cond=None, x_T=None, **kwargs):
-    """test_geo4d.py:118-274 for modality 'pc_ray_cross_depth'. ``cond`` = {"c_crossattn": [ctx [B,77+16T,1024]],
-    "c_concat": [z_video [B,4,T,h,w]]} must be supplied (the CLIP / VAE-encode front-end is N3). Returns
-    [B, n_samples, 11, T, H, W] like the reference."""
-    if multiple_cond_cfg or loop or interp:
-        raise NotImplementedError("multiple_cond_cfg / loop / interp are outside the shipped Geo4D inference settings")
+    """test_geo4d.py:118-274 for modality 'pc_ray_cross_depth'. ``cond`` = {"c_crossattn": [ctx [B,77+16T,1024]]} must be
+    supplied (the OpenCLIP / Resampler front-end is N3); ``c_concat`` is taken from ``cond`` if present, otherwise computed
+    from ``videos`` [B,3,T,H,W] by the VAE encoder like the reference does. ``multiple_cond_cfg`` selects the 3-way guidance
+    sampler. Returns [B, n_samples, 11, T, H, W] like the reference."""
+    if loop or interp:
+        raise NotImplementedError("loop / interp raise in the reference too (test_geo4d.py:161-162)")
     batch_size = noise_shape[0]
     fs_t = torch.tensor([fs] * batch_size, dtype=torch.long, device=model.device)
     if cond is None:
-        model.get_learned_conditioning(prompts)       # raises: N3
+        model.get_learned_conditioning(prompts)       # raises: the OpenCLIP / Resampler front-end is N3
+    if "c_concat" not in cond and model.model.conditioning_key == "hybrid":
+        cond = dict(cond, c_concat=[get_latent_z(model, videos)])       # test_geo4d.py:159-170 (modality != img_vidpc)
     uc = None
     if unconditional_guidance_scale != 1.0:
         uc = kwargs.pop("unconditional_conditioning", None)
         if uc is None:
             raise NotImplementedError("CFG needs precomputed unconditional conditioning (front-end is N3)")
-    kwargs.update({"unconditional_conditioning_img_nonetext": None})
-    sampler = DDIMSampler(model)
+    if multiple_cond_cfg and cfg_img != 1.0 and uc is not None:
+        if kwargs.get("unconditional_conditioning_img_nonetext") is None:
+            raise NotImplementedError("multiple_cond_cfg needs precomputed unconditional_conditioning_img_nonetext (front-end is N3)")
+    else:
+        kwargs.update({"unconditional_conditioning_img_nonetext": None})
+    sampler = (DDIMSamplerMulticond if multiple_cond_cfg else DDIMSampler)(model)
     variants = []
     for _ in range(n_samples):
         samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:], verbose=False,
