@@ -110,6 +110,51 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
     return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)
 
 
+@torch.no_grad()
+def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_length=16, seed=123, ddim_steps=50, ddim_eta=0.0,
+             unconditional_guidance_scale=1.0, fs=24, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+             prompts=("Output a video that assigns each 3D location in the world a consistent color.",),
+             synthesize=None, gather=True, **kwargs):
+    """The window loop of ``run_inference`` (test_geo4d.py:396-443), data-parallel over windows.
+
+    ``videos_all`` [1,3,T,H,W] in [-1,1]; ``context`` = cross-attention context [1, 77+16*video_length, D] (the OpenCLIP /
+    Resampler front-end is N3; the shipped config feeds a fixed prompt and a zero image, so it is window-independent) or a
+    callable ``context(window_frames) -> tensor``. Windows come from ``window_slices`` (tail window always appended), window
+    ``w`` runs on rank ``w % world`` and ONE all-gather returns every window's decoded maps on every rank:
+    ``(slices, maps [n_windows, 11, video_length, H, W])``. Noise and posterior sampling are seeded PER WINDOW
+    (``seed``, window index), so the result does not depend on the number of GPUs — unlike the reference's single
+    sequential RNG stream, which cannot be reproduced across a sharded loop."""
+    from . import dist as gdist
+    synthesize = synthesize or image_guided_synthesis
+    B, C, T, H, W = videos_all.shape
+    if B != 1:
+        raise ValueError("run_clip: one clip at a time (the reference asserts bs == 1, test_geo4d.py:354-356)")
+    slices = window_slices(T, stride, video_length)
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    channels = model.model.diffusion_model.out_channels
+    noise_shape = [B, channels, video_length, H // 8, W // 8]
+    local = []
+    for wi in gdist.shard_windows(len(slices), rank, world):
+        videos = videos_all[:, :, slices[wi]].clone()
+        wseed = (int(seed) * 1000003 + wi) % (2 ** 63 - 1)
+        x_T = torch.randn(noise_shape, generator=torch.Generator().manual_seed(wseed)).to(videos_all.device)
+        ctx = context(videos) if callable(context) else context
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(wseed)                                   # posterior sampling noise of the VAE encode
+            maps = synthesize(model, list(prompts), videos, noise_shape, n_samples=1, ddim_steps=ddim_steps, ddim_eta=ddim_eta,
+                              unconditional_guidance_scale=unconditional_guidance_scale, fs=fs, timestep_spacing=timestep_spacing,
+                              guidance_rescale=guidance_rescale, pointmap_vae=pointmap_vae, cond={"c_crossattn": [ctx]},
+                              x_T=x_T, **kwargs)
+        assert maps.shape[1] == 1, "only support variants size = 1"
+        local.append(maps[:, 0])
+    like = videos_all.new_zeros((0, 11, video_length, H, W), dtype=torch.float32)
+    local = torch.cat(local, 0) if local else like
+    if not gather:
+        return slices, local
+    return slices, gdist.all_gather_windows(local, len(slices), rank=rank, world=world)
+
+
 def get_sky_mask(x, sky_value=1.05, eps=0.05):
     lo, hi = sky_value - eps, sky_value + eps
     return ((x > lo) & (x < hi)).all(dim=-1, keepdim=True)

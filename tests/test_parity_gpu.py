@@ -279,6 +279,29 @@ def test_synthesis_encodes_video_when_c_concat_is_missing(dev):
     assert torch.equal(a, b)
 
 
+def test_run_clip_windows(dev):
+    """run_clip = the window loop of run_inference (test_geo4d.py:396-443) on the HIP path: 20 frames -> windows (0,16),
+    (4,20) and the always-appended tail (4,20); deterministic; window 0 equals a direct image_guided_synthesis call with that
+    window's seeds."""
+    from geo4d_amd.pipeline import image_guided_synthesis, run_clip
+    m, u, _ = _diffusion(dev, "bf16")
+    gen = torch.Generator().manual_seed(8)
+    video = (torch.rand((1, 3, 20, 64, 64), generator=gen) * 2 - 1).to(dev)
+    ctx = torch.randn((1, 77 + 16 * 16, u["unet_config"]["context_dim"]), generator=gen).to(dev)
+    kw = dict(ddim_steps=3, seed=123)
+    slices, maps = run_clip(m, video, ctx, **kw)
+    _, maps2 = run_clip(m, video, lambda frames: ctx, **kw)
+    assert [(s.start, s.stop) for s in slices] == [(0, 16), (4, 20), (4, 20)]
+    assert maps.shape == (3, 11, 16, 64, 64) and torch.isfinite(maps).all() and torch.equal(maps, maps2)
+    assert not torch.equal(maps[1], maps[2])            # same frames, different window index => different noise
+    wseed = 123 * 1000003 + 0
+    x_T = torch.randn([1, 16, 16, 8, 8], generator=torch.Generator().manual_seed(wseed)).to(dev)
+    torch.manual_seed(wseed)
+    direct = image_guided_synthesis(m, [""], video[:, :, 0:16], [1, 16, 16, 8, 8], n_samples=1, ddim_steps=3, ddim_eta=0.0, fs=24,
+                                    timestep_spacing="uniform_trailing", guidance_rescale=0.7, cond={"c_crossattn": [ctx]}, x_T=x_T)
+    assert torch.equal(direct[:, 0], maps[0:1])
+
+
 def test_stochastic_ddim_runs(dev):
     """eta > 0 draws torch noise per step (no hipGraph); RNG streams differ from the CPU reference, so only sanity here."""
     from geo4d_amd.ddim import DDIMSampler
