@@ -84,6 +84,9 @@ SIGNATURES = {
                                   C.c_void_p]),
     "geo4d_advance_index": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_gather_timestep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "geo4d_plucker_cameras_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "geo4d_plucker_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_void_p]),
     "geo4d_last_error": (C.c_char_p, []),
     "geo4d_abi_version": (C.c_int, []),
 }

@@ -393,3 +393,21 @@ def gather_timestep(idx, table, ts):
     _lib.check(lib.geo4d_gather_timestep(idx.data_ptr(), table.data_ptr(), ts.data_ptr(), ts.numel(), _stream()),
                "geo4d_gather_timestep")
     return ts
+
+
+def plucker_cameras(raymap, crossmap):
+    """raymap, crossmap: fp32 [1, 3, T, H, W] (may be channel views of the decoded [B, 11, T, H, W] tensor) -> P_c2w [T, 4, 4]."""
+    lib = _lib.load()
+    _dev(raymap, "raymap"); _dev(crossmap, "crossmap")
+    assert raymap.dtype == torch.float32 and crossmap.dtype == torch.float32 and raymap.shape == crossmap.shape
+    B, Cc, T, H, W = raymap.shape
+    assert B == 1 and Cc == 3, raymap.shape
+    for m in (raymap, crossmap):
+        assert m.stride(4) == 1 and m.stride(3) == W, "pixel planes must be contiguous"
+    assert raymap.stride(1) == crossmap.stride(1) and raymap.stride(2) == crossmap.stride(2)
+    need = lib.geo4d_plucker_cameras_workspace(T, H, W)
+    ws = torch.empty(need // 8, device=raymap.device, dtype=torch.float64)
+    out = torch.empty((T, 4, 4), device=raymap.device, dtype=torch.float32)
+    _lib.check(lib.geo4d_plucker_cameras(raymap.data_ptr(), crossmap.data_ptr(), raymap.stride(1), raymap.stride(2), T, H, W,
+                                         ws.data_ptr(), need, out.data_ptr(), _stream()), "geo4d_plucker_cameras")
+    return out

@@ -114,14 +114,16 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
 def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_length=16, seed=123, ddim_steps=50, ddim_eta=0.0,
              unconditional_guidance_scale=1.0, fs=24, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
              prompts=("Output a video that assigns each 3D location in the world a consistent color.",),
-             synthesize=None, gather=True, **kwargs):
+             synthesize=None, gather=True, with_cameras=False, **kwargs):
     """The window loop of ``run_inference`` (test_geo4d.py:396-443), data-parallel over windows.
 
     ``videos_all`` [1,3,T,H,W] in [-1,1]; ``context`` = cross-attention context [1, 77+16*video_length, D] (the OpenCLIP /
     Resampler front-end is N3; the shipped config feeds a fixed prompt and a zero image, so it is window-independent) or a
     callable ``context(window_frames) -> tensor``. Windows come from ``window_slices`` (tail window always appended), window
     ``w`` runs on rank ``w % world`` and ONE all-gather returns every window's decoded maps on every rank:
-    ``(slices, maps [n_windows, 11, video_length, H, W])``. Noise and posterior sampling are seeded PER WINDOW
+    ``(slices, maps [n_windows, 11, video_length, H, W])``; with ``with_cameras`` also the per-window camera-to-world
+    matrices ``traj [n_windows, video_length, 4, 4]`` from the ray / ray-moment maps (test_geo4d.py:455-458, computed on the
+    device by ``geo4d_amd.rays``, no host sync in the loop). Noise and posterior sampling are seeded PER WINDOW
     (``seed``, window index), so the result does not depend on the number of GPUs — unlike the reference's single
     sequential RNG stream, which cannot be reproduced across a sharded loop."""
     from . import dist as gdist
@@ -134,7 +136,7 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     channels = model.model.diffusion_model.out_channels
     noise_shape = [B, channels, video_length, H // 8, W // 8]
-    local = []
+    local, traj = [], []
     for wi in gdist.shard_windows(len(slices), rank, world):
         videos = videos_all[:, :, slices[wi]].clone()
         wseed = (int(seed) * 1000003 + wi) % (2 ** 63 - 1)
@@ -148,11 +150,17 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
                               x_T=x_T, **kwargs)
         assert maps.shape[1] == 1, "only support variants size = 1"
         local.append(maps[:, 0])
+        if with_cameras:
+            from .rays import raymap_to_camera_matrix
+            traj.append(raymap_to_camera_matrix(maps[:, 0, 4:7], maps[:, 0, 7:10])[None])
     like = videos_all.new_zeros((0, 11, video_length, H, W), dtype=torch.float32)
     local = torch.cat(local, 0) if local else like
-    if not gather:
-        return slices, local
-    return slices, gdist.all_gather_windows(local, len(slices), rank=rank, world=world)
+    out = [local]
+    if with_cameras:
+        out.append(torch.cat(traj, 0) if traj else videos_all.new_zeros((0, video_length, 4, 4), dtype=torch.float32))
+    if gather:
+        out = [gdist.all_gather_windows(o, len(slices), rank=rank, world=world) for o in out]
+    return (slices, *out)
 
 
 def get_sky_mask(x, sky_value=1.05, eps=0.05):

@@ -135,6 +135,16 @@ int geo4d_advance_index(int* idx, int delta, void* stream);
  * the captured step graph is step-independent. */
 int geo4d_gather_timestep(const int* idx, const long* table, long* ts, int B, void* stream);
 
+/* Plücker ray map -> camera-to-world matrices of one window. replaces raymap_to_camera_matrix
+ * (scripts/evaluation/test_geo4d.py:539-557) -> cameras_from_plucker / rays_to_cameras (utils/rays.py:387-433, 301-368) ->
+ * intersect_skew_lines_high_dim (utils/normalize.py:25-51) + compute_optimal_rotation_alignment (utils/rays.py:579-595), which the
+ * reference runs on the host. ray / moment: fp32 planes [3][T][H][W] addressed as base + c*channel_stride + t*frame_stride + y*W + x
+ * (so they can be channel views of the decoded [B,11,T,H,W] tensor); frame 0 is the reference frame; the maps are centre-cropped to
+ * min(H,W)^2 like the reference. P_c2w: [T][4][4] fp32 row-major. workspace: geo4d_plucker_cameras_workspace bytes, 8-byte aligned. */
+size_t geo4d_plucker_cameras_workspace(int T, int H, int W);
+int geo4d_plucker_cameras(const float* ray, const float* moment, long channel_stride, long frame_stride, int T, int H, int W,
+                          void* workspace, size_t workspace_bytes, float* P_c2w, void* stream);
+
 const char* geo4d_last_error(void);
 int geo4d_abi_version(void);
 

@@ -141,9 +141,69 @@ def encode_fixtures():
                     shapes={k: tuple(v.shape) for k, v in vae.state_dict().items()}), os.path.join(HERE, "vae_encode_tiny.pt"))
 
 
+def synthetic_ray_maps(T, H, W, seed, noise=0.01):
+    """Plücker maps of a smooth synthetic camera path (directions through a pinhole, moments = c x d) + noise: the kind of
+    input the decoder hands to raymap_to_camera_matrix, with a well-defined answer."""
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.linspace(-0.5, 0.5, H), torch.linspace(-0.8, 0.8, W), indexing="ij")
+    cam_dirs = torch.nn.functional.normalize(torch.stack([xs, ys, torch.ones_like(xs)], -1), dim=-1)       # [H, W, 3]
+    rays, moms = [], []
+    for t in range(T):
+        ang = torch.tensor([0.05 * t, -0.08 * t, 0.03 * t])
+        cx, cy, cz = torch.cos(ang); sx, sy, sz = torch.sin(ang)
+        Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        R = (Rz @ Ry @ Rx).float()
+        c = torch.tensor([0.1 * t, 0.02 * t * t, -0.05 * t])
+        d = cam_dirs @ R.T
+        m = torch.cross(c.expand_as(d), d, dim=-1)
+        rays.append(d * (1.0 + 0.3 * torch.rand((H, W, 1), generator=g)) + noise * torch.randn(d.shape, generator=g))   # un-normalised, like a decoder output
+        moms.append(m + noise * torch.randn(d.shape, generator=g))
+    to = lambda L: torch.stack(L).permute(3, 0, 1, 2)[None].contiguous()      # [1, 3, T, H, W]
+    return to(rays), to(moms)
+
+
+def rays_fixtures():
+    """`python tests/golden/generate.py rays` -> rays.pt: the reference's raymap_to_camera_matrix (test_geo4d.py:539-557 ->
+    utils/rays.py cameras_from_plucker) on synthetic Plücker maps. pytorch3d is absent here; its PerspectiveCameras is used by
+    that code only as a container of R / T / focal_length, so it is stubbed as one."""
+    for name in ("ipdb",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    p3, rend, tr = types.ModuleType("pytorch3d"), types.ModuleType("pytorch3d.renderer"), types.ModuleType("pytorch3d.transforms")
+
+    class PerspectiveCameras:
+        def __init__(self, focal_length=None, R=None, T=None, device=None, **kw):
+            n = len(focal_length)
+            self.focal_length = focal_length
+            self.R = torch.eye(3).repeat(n, 1, 1) if R is None else R
+            self.T = torch.zeros(n, 3) if T is None else T
+
+        def __len__(self):
+            return self.R.shape[0]
+
+        def clone(self):
+            return PerspectiveCameras(self.focal_length, self.R.clone(), self.T.clone())
+    rend.PerspectiveCameras, rend.RayBundle = PerspectiveCameras, object
+    tr.Rotate = tr.Translate = object
+    sys.modules.update({"pytorch3d": p3, "pytorch3d.renderer": rend, "pytorch3d.transforms": tr})
+    from utils.rays import cameras_from_plucker
+    ns = script_functions({"raymap_to_camera_matrix"})
+    ns["cameras_from_plucker"] = cameras_from_plucker
+    cases = {}
+    for name, (T, H, W, seed) in {"wide_4x16x24": (4, 16, 24, 1), "tall_3x24x16": (3, 24, 16, 2), "wide_16x8x20": (16, 8, 20, 3)}.items():   # H == W raises UnboundLocalError in the reference (rays.py:399-417)
+        ray, mom = synthetic_ray_maps(T, H, W, seed)
+        with torch.no_grad():
+            P = ns["raymap_to_camera_matrix"](ray, mom)
+        print(name, tuple(P.shape), P[-1, :3, 3].tolist())
+        cases[name] = dict(raymap=ray, crossmap=mom, P_c2w=P)
+    torch.save(cases, os.path.join(HERE, "rays.pt"))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "encode":
         return encode_fixtures()
+    if len(sys.argv) > 1 and sys.argv[1] == "rays":
+        return rays_fixtures()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     from lvdm.models.samplers.ddim import DDIMSampler

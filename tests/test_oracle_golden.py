@@ -121,6 +121,18 @@ def test_posterior_object_matches_reference_formulas():
     assert torch.equal(d.sample(), mean) and float(d.kl()) == 0.0
 
 
+def test_plucker_cameras_oracle_matches_reference():
+    """oracle/rays.py vs camera matrices produced by the reference's own raymap_to_camera_matrix / cameras_from_plucker."""
+    from oracle import rays as orays
+    for name, c in load("rays.pt").items():
+        P = orays.raymap_to_camera_matrix(c["raymap"], c["crossmap"])
+        err = (P.float() - c["P_c2w"]).abs().max().item()
+        assert P.shape == c["P_c2w"].shape and err < 2e-5, (name, err)
+        R = P[:, :3, :3]
+        assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=R.dtype).expand_as(R), atol=1e-9)
+        assert torch.allclose(torch.linalg.det(R), torch.ones(R.shape[0], dtype=R.dtype))
+
+
 def test_window_indices_bit_exact():
     g = load("glue.pt")
     for (T, stride), ref in g["windows"].items():

@@ -290,7 +290,10 @@ def test_run_clip_windows(dev):
     ctx = torch.randn((1, 77 + 16 * 16, u["unet_config"]["context_dim"]), generator=gen).to(dev)
     kw = dict(ddim_steps=3, seed=123)
     slices, maps = run_clip(m, video, ctx, **kw)
-    _, maps2 = run_clip(m, video, lambda frames: ctx, **kw)
+    _, maps2, traj = run_clip(m, video, lambda frames: ctx, with_cameras=True, **kw)
+    assert traj.shape == (3, 16, 4, 4) and torch.isfinite(traj).all()
+    Rm = traj[:, :, :3, :3].double()
+    assert torch.allclose(Rm @ Rm.transpose(-1, -2), torch.eye(3, dtype=torch.float64, device=dev).expand_as(Rm), atol=1e-5)
     assert [(s.start, s.stop) for s in slices] == [(0, 16), (4, 20), (4, 20)]
     assert maps.shape == (3, 11, 16, 64, 64) and torch.isfinite(maps).all() and torch.equal(maps, maps2)
     assert not torch.equal(maps[1], maps[2])            # same frames, different window index => different noise
@@ -300,6 +303,42 @@ def test_run_clip_windows(dev):
     direct = image_guided_synthesis(m, [""], video[:, :, 0:16], [1, 16, 16, 8, 8], n_samples=1, ddim_steps=3, ddim_eta=0.0, fs=24,
                                     timestep_spacing="uniform_trailing", guidance_rescale=0.7, cond={"c_crossattn": [ctx]}, x_T=x_T)
     assert torch.equal(direct[:, 0], maps[0:1])
+
+
+def test_plucker_cameras_vs_reference_golden(dev):
+    """raymap_to_camera_matrix on the device (csrc/rays.hip) vs matrices produced by the reference's own
+    functions (fixtures), vs the fp64 oracle on a larger window taken as channel views of a decoded [1,11,T,H,W] tensor, and on
+    a square frame (where the reference itself raises)."""
+    from geo4d_amd.rays import cameras_from_plucker, raymap_to_camera_matrix
+    from oracle import rays as orays
+    for name, c in load("rays.pt").items():
+        P = raymap_to_camera_matrix(c["raymap"].to(dev), c["crossmap"].to(dev))
+        err = (P.cpu() - c["P_c2w"]).abs().max().item()
+        print(f"[plucker {name}] max abs err vs reference = {err:.2e}")
+        assert P.shape == c["P_c2w"].shape and err < 5e-5
+    for (T, H, W) in ((16, 64, 96), (16, 40, 40)):
+        gen = torch.Generator().manual_seed(T + H)
+        # synthetic smooth path: directions through a pinhole + noise (same recipe as the fixture generator, inlined)
+        ys, xs = torch.meshgrid(torch.linspace(-0.5, 0.5, H), torch.linspace(-0.8, 0.8, W), indexing="ij")
+        cam = torch.nn.functional.normalize(torch.stack([xs, ys, torch.ones_like(xs)], -1), dim=-1)
+        maps = torch.zeros((1, 11, T, H, W))
+        for t in range(T):
+            a = torch.tensor(0.04 * t)
+            R = torch.tensor([[torch.cos(a), 0, torch.sin(a)], [0, 1, 0], [-torch.sin(a), 0, torch.cos(a)]])
+            cc = torch.tensor([0.1 * t, -0.03 * t, 0.02 * t * t])
+            d = cam @ R.T
+            maps[0, 4:7, t] = (d * 1.3 + 0.01 * torch.randn(d.shape, generator=gen)).permute(2, 0, 1)
+            maps[0, 7:10, t] = (torch.cross(cc.expand_as(d), d, dim=-1) + 0.01 * torch.randn(d.shape, generator=gen)).permute(2, 0, 1)
+        md = maps.to(dev)
+        P = raymap_to_camera_matrix(md[:, 4:7], md[:, 7:10])
+        ref = orays.raymap_to_camera_matrix(maps[:, 4:7], maps[:, 7:10])
+        err = (P.cpu().double() - ref).abs().max().item()
+        print(f"[plucker {T}x{H}x{W}] max abs err vs oracle = {err:.2e}")
+        assert err < 5e-5
+        R_, T_, c_ = cameras_from_plucker(md[:, 4:7], md[:, 7:10])
+        assert torch.allclose(c_.cpu().double(), ref[:, :3, 3], atol=5e-5) and R_.shape == (T, 3, 3) and T_.shape == (T, 3)
+    with pytest.raises(RuntimeError):
+        raymap_to_camera_matrix(torch.zeros((1, 3, 2, 8, 11), device=dev), torch.zeros((1, 3, 2, 8, 11), device=dev))   # odd |H - W|
 
 
 def test_stochastic_ddim_runs(dev):
