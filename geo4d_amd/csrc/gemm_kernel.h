@@ -26,7 +26,7 @@ __device__ __forceinline__ float load_res(const void* R, long idx, int dt) {
 template <int BM, int BN, int WM, int WN, int ST>
 constexpr int stage_bytes() {
     constexpr int ring = ST * (BM + BN) * PITCH;
-    constexpr int epi = WM * WN * 32 * (BN / WN + 4) * 4;   // one fp32 32 x WTN transpose block per wave
+    constexpr int epi = WM * WN * 32 * ((((BN / WN / 32) % 2 == 0) ? 64 : 32) + 4) * 4;   // one fp32 32 x CG transpose block per wave
     return ring > epi ? ring : epi;
 }
 template <int BM, int BN, int WM, int WN, int ST>
@@ -43,8 +43,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     constexpr int ACH = BM * BKC / NT, BCH = BN * BKC / NT;
     constexpr int RSTEP = NT / 8;                 // rows covered by one staging pass of the whole workgroup
     constexpr int WTM = MB * 32, WTN = NB * 32;   // wave tile
-    constexpr int SP = WTN + 4;                   // fp32 staging pitch (floats)
-    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    constexpr int CG = (NB % 2 == 0) ? 64 : 32;   // columns staged per epilogue pass
+    constexpr int NG = WTN / CG;
+    constexpr int SP = CG + 4;                    // fp32 staging pitch (floats)
+    static_assert(WM * WN == 4 || WM * WN == 5 || WM * WN == 8 || WM * WN == 10, "4, 5, 8 or 10 waves");
+    static_assert((BM * BKC) % NT == 0 && (BN * BKC) % NT == 0 && (NT / 8) % 2 == 0, "staging passes must tile the panel");
     static_assert(MB >= 1 && NB >= 1 && ACH >= 1 && BCH >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* rowpix = (int*)(smem + stage_bytes<BM, BN, WM, WN, ST>());
@@ -87,15 +90,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
 
     const int ccol = tid & 7;
     const int r0 = tid >> 3;
-    // source-side swizzle: LDS slot `ccol` of row r holds global chunk ccol ^ ((r >> 1) & 7); rows advance by 32 per
-    // staging pass, so the XOR term is a per-thread constant
+    // source-side swizzle: LDS slot `ccol` of row r holds global chunk ccol ^ ((r >> 1) & 7). Rows advance by RSTEP per staging
+    // pass; when RSTEP / 2 is a multiple of 8 (4, 8, 10 waves) the XOR term is a per-thread constant, otherwise (5 waves) it
+    // alternates with the pass index, which is a compile-time constant of the unrolled issue loop.
     const int csrc = (ccol ^ ((r0 >> 1) & 7)) * EPC;
+    constexpr bool SWZ_CONST = ((RSTEP / 2) % 8) == 0;
+    auto csrc_of = [&](int i) { return SWZ_CONST ? csrc : (ccol ^ (((r0 + i * RSTEP) >> 1) & 7)) * EPC; };
     const T* __restrict__ Z = (const T*)p.zeros;
     const T* wptr[BCH];
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
         const int n = tn * BN + r0 + i * RSTEP;
-        wptr[i] = n < p.N ? W + (long)n * p.ldw + csrc : nullptr;
+        wptr[i] = n < p.N ? W + (long)n * p.ldw + csrc_of(i) : nullptr;
     }
 
     // K range of this workgroup (split-K over gridDim.z)
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     auto issue_piece = [&](int buf, int j) {
         char* base = smem + buf * (BM + BN) * PITCH + wave * 1024;
         if (j < ACH) {
-            const T* src = pix[j] >= 0 ? A + (long)pix[j] * p.lda + c0 + csrc : Z;
+            const T* src = pix[j] >= 0 ? A + (long)pix[j] * p.lda + c0 + csrc_of(j) : Z;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + j * RSTEP * PITCH), 16, 0, 0);
         } else {
@@ -300,12 +306,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
         return;
     }
 
-    // staged path: registers -> fp32 LDS block [32 m][WTN n] private to the wave -> coalesced 16-byte rows, one 32-row
-    // block of the wave tile at a time (the staging area is 32 x (WTN + 4) floats per wave, so the 256x256 tile fits)
+    // staged path: registers -> fp32 LDS block [32 m][CG n] private to the wave -> coalesced 16-byte rows. One 32-row block of
+    // the wave tile and one group of CG columns (64, or 32 when the wave tile is an odd number of 32-column blocks wide) at a
+    // time, so the staging area stays 32 x (CG + 4) floats per wave whatever the tile (256x256 and 160x320 tiles fit).
     float* stg = (float*)smem + wave * (32 * SP);
-    const int ncols_w = geglu ? WTN / 2 : WTN;             // staged columns per wave
     const int ocol_w0 = geglu ? (n_w0 >> 1) : n_w0;
-    const int cpr = ncols_w / 8;                 // 8-element chunks per staged row (16, 8, 4 or 2)
+    constexpr int BPG = CG / 32;                              // 32-column accumulator blocks per group
+    const int gcols = geglu ? CG / 2 : CG;                   // staged (= stored) columns per group
+    const int cpr = gcols / 8;                                // 8-element chunks per staged row (8, 4 or 2)
     const int rows_per_pass = 64 / cpr;
     const int lc = lane % cpr, lr = lane / cpr;
 #pragma unroll
@@ -313,92 +321,94 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
         const int m = m_w0 + a * 32 + li;
         const float brow = (!partial && p.bias && p.bias_per_row && m < p.M) ? p.bias[m] : 0.f;
         const long rboff = (!partial && p.rowbias && m < p.M) ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
-        if (geglu) {
-            if constexpr (NB % 2 == 0) {
-                // packed GEGLU weights interleave value / gate in 32-column blocks: block 2j = value, 2j + 1 = gate
 #pragma unroll
-                for (int b2 = 0; b2 < NB / 2; ++b2)
+        for (int cg = 0; cg < NG; ++cg) {
+            if (geglu) {
+                if constexpr (BPG == 2) {
+                    // packed GEGLU weights interleave value / gate in 32-column blocks: block 2j = value, 2j + 1 = gate
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int nn = n_w0 + 64 * b2 + 8 * q + 4 * g;
+                        const int nn = n_w0 + 64 * cg + 8 * q + 4 * g;
                         f32x4 o;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const bool ok = nn + 32 + j < p.N;
-                            const float xv = acc[a][2 * b2][4 * q + j] * p.alpha + ((p.bias && ok) ? p.bias[nn + j] : 0.f);
-                            const float gv = acc[a][2 * b2 + 1][4 * q + j] * p.alpha + ((p.bias && ok) ? p.bias[nn + 32 + j] : 0.f);
+                            const float xv = acc[a][2 * cg][4 * q + j] * p.alpha + ((p.bias && ok) ? p.bias[nn + j] : 0.f);
+                            const float gv = acc[a][2 * cg + 1][4 * q + j] * p.alpha + ((p.bias && ok) ? p.bias[nn + 32 + j] : 0.f);
                             o[j] = xv * gelu_erf_f(gv);
                         }
-                        *(f32x4*)(stg + li * SP + 32 * b2 + 8 * q + 4 * g) = o;
+                        *(f32x4*)(stg + li * SP + 8 * q + 4 * g) = o;
                     }
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n_w0 + b * 32 + 8 * q + 4 * g;
-                    f32x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = acc[a][b][4 * q + j];
-                        if (!partial) {
-                            v = v * p.alpha + brow;
-                            if (n + j < p.N) {
-                                if (p.bias && !p.bias_per_row) v += p.bias[n + j];
-                                if (p.rowbias) v += p.rowbias[rboff + n + j];
-                            }
-                            if (p.act == 1) v = silu_f(v);
-                        }
-                        o[j] = v;
-                    }
-                    *(f32x4*)(stg + li * SP + b * 32 + 8 * q + 4 * g) = o;
                 }
-        }
-        // the block is private to this wave and LDS operations of one wave execute in order: no workgroup barrier needed,
-        // only a fence that keeps the compiler from moving the reads above the writes (and the next block's writes above these reads)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // read back: 8 output elements per lane (two 16-byte LDS reads)
-        for (int rr = lr; rr < 32; rr += rows_per_pass) {
-            const int mo = m_w0 + a * 32 + rr;
-            const int n = ocol_w0 + lc * 8;
-            if (mo >= p.M || n >= nout) continue;
-            const f32x4 v0 = *(const f32x4*)(stg + rr * SP + lc * 8);
-            const f32x4 v1 = *(const f32x4*)(stg + rr * SP + lc * 8 + 4);
-            float e[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const long oidx = obase + (long)mo * ldo + n;
-            if (odt == GEO4D_F32) {
-                if (!partial && p.R) {
-                    const float* rp = (const float*)p.R + bz * p.r_bs + (long)mo * p.ldr + n;
-                    const f32x4 r0v = *(const f32x4*)rp, r1v = *(const f32x4*)(rp + 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { e[j] += r0v[j]; e[4 + j] += r1v[j]; }
-                }
-                f32x4 o0 = {e[0], e[1], e[2], e[3]}, o1 = {e[4], e[5], e[6], e[7]};
-                *(f32x4*)((float*)O + oidx) = o0;
-                *(f32x4*)((float*)O + oidx + 4) = o1;
-            } else if (odt == GEO4D_BF16) {
-                if (p.R) {
-                    float r[8];
-                    chunk_to_f32<bf16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)mo * p.ldr + n), r);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) e[j] += r[j];
-                }
-                *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<bf16_t>(e);
             } else {
-                if (p.R) {
-                    float r[8];
-                    chunk_to_f32<f16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)mo * p.ldr + n), r);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) e[j] += r[j];
-                }
-                *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<f16_t>(e);
+                for (int bb = 0; bb < BPG; ++bb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = cg * BPG + bb;
+                        const int n = n_w0 + b * 32 + 8 * q + 4 * g;
+                        f32x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[a][b][4 * q + j];
+                            if (!partial) {
+                                v = v * p.alpha + brow;
+                                if (n + j < p.N) {
+                                    if (p.bias && !p.bias_per_row) v += p.bias[n + j];
+                                    if (p.rowbias) v += p.rowbias[rboff + n + j];
+                                }
+                                if (p.act == 1) v = silu_f(v);
+                            }
+                            o[j] = v;
+                        }
+                        *(f32x4*)(stg + li * SP + bb * 32 + 8 * q + 4 * g) = o;
+                    }
             }
+            // the block is private to this wave and LDS operations of one wave execute in order: no workgroup barrier needed, only a
+            // fence that keeps the compiler from moving the reads above the writes (and the next group's writes above these reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // read back: 8 output elements per lane (two 16-byte LDS reads)
+            for (int rr = lr; rr < 32; rr += rows_per_pass) {
+                const int mo = m_w0 + a * 32 + rr;
+                const int n = ocol_w0 + cg * gcols + lc * 8;
+                if (mo >= p.M || n >= nout) continue;
+                const f32x4 v0 = *(const f32x4*)(stg + rr * SP + lc * 8);
+                const f32x4 v1 = *(const f32x4*)(stg + rr * SP + lc * 8 + 4);
+                float e[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const long oidx = obase + (long)mo * ldo + n;
+                if (odt == GEO4D_F32) {
+                    if (!partial && p.R) {
+                        const float* rp = (const float*)p.R + bz * p.r_bs + (long)mo * p.ldr + n;
+                        const f32x4 r0v = *(const f32x4*)rp, r1v = *(const f32x4*)(rp + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { e[j] += r0v[j]; e[4 + j] += r1v[j]; }
+                    }
+                    f32x4 o0 = {e[0], e[1], e[2], e[3]}, o1 = {e[4], e[5], e[6], e[7]};
+                    *(f32x4*)((float*)O + oidx) = o0;
+                    *(f32x4*)((float*)O + oidx + 4) = o1;
+                } else if (odt == GEO4D_BF16) {
+                    if (p.R) {
+                        float r[8];
+                        chunk_to_f32<bf16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)mo * p.ldr + n), r);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) e[j] += r[j];
+                    }
+                    *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<bf16_t>(e);
+                } else {
+                    if (p.R) {
+                        float r[8];
+                        chunk_to_f32<f16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)mo * p.ldr + n), r);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) e[j] += r[j];
+                    }
+                    *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<f16_t>(e);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -440,6 +450,10 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     constexpr int smem = smem_bytes<BM, BN, WM, WN, ST>();
     static bool attr_set = false;
     auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, ST>;
+    if (p.act == 2 && ((BN / WN / 32) & 1)) {
+        geo4d_set_error("conv_gemm: GEGLU needs wave tiles that are a multiple of 64 columns wide (this tile has an odd number of 32-column blocks)");
+        return GEO4D_EINVAL;
+    }
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
@@ -473,10 +487,10 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
         // flops a CU can retire per microsecond are (bytes in flight) x (flops per byte of the tile shape).
         //   11: 256x128, 8 waves, 2 stages     12: 256x128, 8 waves, 3 stages (2 stages in flight)
         //   13: 256x256, 8 waves, 2 stages (128 flop/B)     14: 128x128, 4 waves, 4 stages (3 in flight)
+        //   16: 160x320, 10 waves (M = 40960, N = 320: 256 tiles = one per CU, each input row and each weight read once per tile)
         // Measured (profiles/r01_gemm_tiles.md): deeper rings (12, 14) never beat their 2-stage twins - the fill rate per CU
         // does not grow with more DMAs in flight - while the fatter tiles (11, 13) do: fewer L2->LDS bytes per flop.
         int sp = 1;
-        if (p.tile_hint > 14) { geo4d_set_error("conv_gemm: unknown tile_hint"); return GEO4D_EINVAL; }
         if (p.split_k > 1) {
             if (!p.workspace || p.act == 2 || p.out_nchw || (p.N % 8) || (size_t)p.split_k * p.batch * p.M * p.N * 4 > p.workspace_bytes ||
                 p.K / (BKC * Elem<T>::EPC) / p.split_k < 1) {
@@ -490,6 +504,8 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             case 12: return launch_cfg<T, 256, 128, 4, 2, 3>(p, sp, stream);
             case 13: return launch_cfg<T, 256, 256, 4, 2, 2>(p, sp, stream);
             case 14: return launch_cfg<T, 128, 128, 2, 2, 4>(p, sp, stream);
+            case 16: return launch_cfg<T, 160, 320, 5, 2, 2>(p, sp, stream);   // 10 waves: all 320 columns of the level-0 layers in ONE tile
+            case 17: return launch_cfg<T, 160, 160, 5, 1, 2>(p, sp, stream);   // 5 waves: M = 10240, N = 640 -> 256 tiles
         }
         geo4d_set_error("conv_gemm: unknown tile_hint");
         return GEO4D_EINVAL;

@@ -62,7 +62,7 @@ import os as _os
 
 _TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950.json")
 _TUNE = None
-_CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
+_CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1), (17, 2), (16, 2), (17, 8), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
 

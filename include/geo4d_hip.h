@@ -55,7 +55,9 @@ typedef struct geo4d_conv_gemm_t {
                             destination tensor; O may point at a channel offset inside it) */
     int tile_hint;       /* 0 auto; 1..5 = 128x128, 128x64, 64x128, 64x64, 128x32 (4 waves, 2-stage ring);
                             8 waves, one tile per CU: 11 = 256x128, 13 = 256x256; deep-ring A/B variants:
-                            12 = 256x128 x 3 stages, 14 = 128x128 x 4 stages. Others: -EINVAL  */
+                            12 = 256x128 x 3 stages, 14 = 128x128 x 4 stages; 16 = 160x320 with 10 waves
+                            (N = 320 layers: one tile per CU at M = 40960), 17 = 160x160 with 5 waves; no
+                            GEGLU on 16 / 17. Others: -EINVAL */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
     int debug_ablate;    /* profiling only: bit0 skip steady-state DMA, bit1 skip MFMA  */
     float alpha;

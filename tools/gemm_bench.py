@@ -121,7 +121,7 @@ def main():
                 vend = e0.elapsed_time(e1) * 1e3 / args.iters
         if args.explore:
             res = []
-            for tile in (1, 2, 3, 4, 11, 12, 13, 14):
+            for tile in (1, 2, 3, 4, 11, 13, 16, 17):
                 for split in (1, 2, 4, 8):
                     try:
                         res.append((timeit(tile=tile, split=split), tile, split))
