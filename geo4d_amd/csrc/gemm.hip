@@ -10,20 +10,23 @@
 // Activations are channels-last tokens [F, H*W, C]; weights are packed [N][taps*Cin] (K-major, tap-major).
 // out[m][n] = epilogue(alpha * sum_k A_gather[m][k] * W[n][k])
 //
-// Structure (256 threads = 4 waves, tile BM x BN x 128 B of K per stage):
+// Structure (kernel template in gemm_kernel.h; 4, 5, 8 or 10 waves, tile BM x BN x 128 B of K per stage; tiles 128x128, 128x64,
+// 64x128, 64x64, 128x32, 256x128, 256x256, 160x320, 160x160 picked per problem by the host's measured table):
 //   * gather table: the source pixel of every (tile row, tap) is resolved ONCE per workgroup into LDS
 //     (-1 = zero padding), so the K loop does one ds_read + one 64-bit mad per 16-byte chunk instead of
 //     re-deriving (frame, y, x), bounds and upsample/stride arithmetic every stage;
 //   * global->LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip and no
 //     ds_write: the ds_write_b128 path tops out at ~79 B/clk/CU and was the limiter of the register-staged version),
-//     2-deep LDS ring, one vmcnt(0)+barrier per stage. The DMA image is lane-linear (8 lanes = one 128-byte row),
+//     2-deep LDS ring, one EXPLICIT `s_waitcnt vmcnt(0)` + barrier per stage (hipcc does not track LDS-DMA and drops the
+//     wait inside loops). K is walked channel-slab major / tap minor so a conv's re-reads of its input hit the XCD's L2.
+//     The DMA image is lane-linear (8 lanes = one 128-byte row),
 //     so bank conflicts are removed by an XOR swizzle applied on the SOURCE address (slot = chunk ^ ((row>>1)&7))
 //     and mirrored on the fragment ds_read_b128 (conflict-free for all four 16-lane service groups);
 //     zero padding = lanes whose tap falls outside the image fetch from a 16-byte zero block;
 //   * swapped MFMA operands: the weight fragment is the MFMA "A" side, the activation fragment the "B" side,
 //     so a lane owns ONE output row m and 4 consecutive output columns n per register quad;
-//   * epilogue through LDS (fp32): bias / row-bias / SiLU / GEGLU applied in registers, tile transposed
-//     through the (now idle) stage buffers, then residual add + rounding + fully coalesced 16-byte stores;
+//   * epilogue through LDS (fp32): bias / row-bias / SiLU / GEGLU applied in registers, each wave transposes its tile through
+//     a private 32 x 64 (or 32 x 32) block of the idle stage buffers, then residual add + rounding + coalesced 16-byte stores;
 //   * optional split-K (gridDim.z) into fp32 partial slabs + a deterministic fixed-order reduce kernel
 //     carrying the epilogue — for the 5x8 / 10x16 levels whose M x N tile count cannot fill 256 CUs;
 //   * workgroup ids remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles with the

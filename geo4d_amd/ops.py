@@ -136,7 +136,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.rowbias_div, p.bias_per_row, p.act = rowbias_div, int(bias_per_row), act
     p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = dt_code(a.dtype), dt_code(out.dtype), int(out_nchw), tile_hint
     p.alpha, p.split_k = alpha, split_k
-    p.debug_ablate = int(_os.environ.get("GEO4D_DEBUG_ABLATE", "0"))
+    p.debug_ablate = 0
     ws, zeros = workspace(a.device)
     p.workspace, p.workspace_bytes, p.zeros = ws.data_ptr(), ws.numel(), zeros.data_ptr()
 

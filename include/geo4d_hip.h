@@ -59,7 +59,7 @@ typedef struct geo4d_conv_gemm_t {
                             (N = 320 layers: one tile per CU at M = 40960), 17 = 160x160 with 5 waves; no
                             GEGLU on 16 / 17. Others: -EINVAL */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
-    int debug_ablate;    /* profiling only: bit0 skip steady-state DMA, bit1 skip MFMA  */
+    int debug_ablate;    /* reserved (was a profiling knob): must be 0                   */
     float alpha;
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);

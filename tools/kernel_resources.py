@@ -5,7 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 files = sys.argv[1:] or sorted(glob.glob(os.path.join(root, "geo4d_amd/csrc/*.hip")))
 for f in files:
     out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{root}/include",
-                          f"-I{root}/geo4d_amd/csrc", "-c", f, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
+                          f"-I{root}/geo4d_amd/csrc", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", f, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                          capture_output=True, text=True).stderr
     cur = {}
     for line in out.splitlines():
