@@ -204,6 +204,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(model, pvae, args.ddim_steps, T, h, w)
         print(json.dumps(res))
     if world > 1:
+        torch.distributed.barrier()        # rank 0 is still timing its conv_gemm timeline: nobody tears the group down under it
         torch.distributed.destroy_process_group()
 
 
