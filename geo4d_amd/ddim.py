@@ -98,7 +98,7 @@ class DDIMSampler(object):
         cfg_img = kwargs.get("cfg_img")
         cfg_img = unconditional_guidance_scale if cfg_img is None else cfg_img
         # static buffers: a captured step graph is reused across sample() calls with the same shapes / conditioning
-        ptrs = lambda c: tuple(t.data_ptr() for v in (c or {}).values() for t in (v if isinstance(v, (list, tuple)) else [v])) if isinstance(c, dict) else ()
+        ptrs = lambda c: tuple((t.data_ptr(), t._version) for v in (c or {}).values() for t in (v if isinstance(v, (list, tuple)) else [v])) if isinstance(c, dict) else ()   # _version: an in-place edit of a conditioning tensor invalidates the captured step (its context K/V are baked in)
         cond_ptrs = ptrs(conditioning) + ((ptrs(unconditional_conditioning), ptrs(uc_img), float(unconditional_guidance_scale),
                                           float(cfg_img), float(guidance_rescale)) if cfg else ())
         key = (size, S, timestep_spacing, cond_ptrs, None if fs is None else fs.data_ptr(), tuple(sorted(kwargs)))
