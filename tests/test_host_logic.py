@@ -133,3 +133,22 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation happens on the host before any launch: bad descriptors return -EINVAL with a message
     p = _lib.ConvGemm()
     assert lib.geo4d_conv_gemm(ctypes.byref(p), None) == -22 and b"conv_gemm" in lib.geo4d_last_error()
+
+
+def test_tuning_table_uses_only_known_tile_hints():
+    """geo4d_amd/tuning/gfx950.json is consulted inside hipGraph capture, where a -EINVAL from geo4d_conv_gemm cannot be
+    recovered by re-tuning: every entry must name a tile hint the C ABI documents and a power-of-two split."""
+    import json
+    import re
+    from geo4d_amd import ops
+    here = os.path.dirname(os.path.abspath(ops.__file__))
+    table = json.load(open(os.path.join(here, "tuning", "gfx950.json")))
+    header = open(os.path.join(os.path.dirname(here), "include", "geo4d_hip.h")).read()
+    documented = {0, 1, 2, 3, 4, 5} | {int(x) for x in re.findall(r"\b(1[1-9]) = \d+x\d+", header)}
+    assert {11, 13, 16} <= documented
+    assert len(table) > 100
+    for key, (tile, split) in table.items():
+        assert tile in documented, (key, tile)
+        assert split in (0, 1, 2, 4, 8, 16), (key, split)
+        assert re.match(r"^\d/\d\|\d+x\d+x\d+\|c\d+\|t\d{3}s\du\d\|a\dr\dn\d\|b\d+$", key), key
+    assert all(t in documented for t, _ in ops._CANDIDATES)
