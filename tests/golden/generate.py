@@ -199,7 +199,21 @@ def rays_fixtures():
     torch.save(cases, os.path.join(HERE, "rays.pt"))
 
 
+def timestep_fixtures():
+    """`python tests/golden/generate.py timesteps` -> timesteps.pt: the reference's make_ddim_timesteps for every spacing
+    method it implements (utils_diffusion.py:56-78) over a sweep of step counts - the integer tables of SURVEY.md §8 (a1)."""
+    from lvdm.models.utils_diffusion import make_ddim_timesteps
+    out = {}
+    for method in ("uniform", "quad", "uniform_trailing"):
+        for S in (1, 2, 3, 5, 7, 10, 20, 25, 50, 100, 200, 250, 333, 500, 999, 1000):
+            out[f"{method}/{S}"] = torch.from_numpy(np.asarray(make_ddim_timesteps(method, S, 1000, verbose=False)).astype(np.int64))
+    torch.save(out, os.path.join(HERE, "timesteps.pt"))
+    print(len(out), "tables")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "timesteps":
+        return timestep_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "encode":
         return encode_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "rays":

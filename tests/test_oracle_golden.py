@@ -36,6 +36,25 @@ def test_schedule_tables_exact():
     assert oddim.ddim_timesteps(5).tolist() == [199, 399, 599, 799, 999]
 
 
+def test_all_timestep_spacings_bit_exact():
+    """make_ddim_timesteps('uniform' | 'quad' | 'uniform_trailing') of the HIP-side sampler AND of the oracle vs tables produced
+    by the reference's own function over a sweep of step counts: integer work, bit-exact."""
+    from geo4d_amd.ddim import make_ddim_timesteps
+    tables = load("timesteps.pt")
+    assert len(tables) == 48
+    for key, ref in tables.items():
+        method, S = key.split("/")
+        got = np.asarray(make_ddim_timesteps(method, int(S), 1000))
+        assert got.dtype == np.int64 and np.array_equal(got, ref.numpy()), key
+        try:
+            o = np.asarray(oddim.ddim_timesteps(int(S), 1000, method))
+        except NotImplementedError:
+            continue
+        assert np.array_equal(o, ref.numpy()), ("oracle", key)
+    with pytest.raises(NotImplementedError):
+        make_ddim_timesteps("cosine", 10, 1000)
+
+
 @pytest.mark.parametrize("case", ["t16_8x8", "b2_t5_8x16"])
 def test_unet_matches_reference(case):
     g = load("unet_tiny.pt")
