@@ -211,7 +211,37 @@ def timestep_fixtures():
     print(len(out), "tables")
 
 
+def ddim_eta_fixtures():
+    """`python tests/golden/generate.py ddim_eta` -> ddim_eta_tiny.pt: the reference DDIMSampler at eta = 1 (the "better visual
+    results" setting of scripts/infer_geo4d.sh) on the tiny LatentDiffusion. The per-step noise comes from torch.randn on the
+    model's device (ddim.py:271, noise_like) = the CPU global generator here, seeded right before sample()."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from lvdm.models.samplers.ddim import DDIMSampler
+
+    class CpuSampler(DDIMSampler):  # ddim.py:18-22 hard-codes torch.device("cuda")
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+    unet_cfg, dd, adp = tiny_configs()
+    model = build_reference(unet_cfg, dd, adp)
+    B, T, h, w = 1, 16, 8, 8
+    x_T = randn((B, 16, T, h, w), 500)
+    cond = {"c_crossattn": [randn((B, 77 + 16 * T, unet_cfg["context_dim"]), 501)], "c_concat": [randn((B, 4, T, h, w), 502)]}
+    fs = torch.tensor([24])
+    with torch.no_grad():
+        torch.manual_seed(777)
+        samples, _ = CpuSampler(model).sample(S=5, conditioning=cond, batch_size=B, shape=[16, T, h, w], verbose=False,
+                                              unconditional_guidance_scale=1.0, unconditional_conditioning=None, eta=1.0, cfg_img=None,
+                                              mask=None, x0=None, fs=fs, x_T=x_T, timestep_spacing="uniform_trailing",
+                                              guidance_rescale=0.7, unconditional_conditioning_img_nonetext=None)
+    print("ddim eta=1", float(samples.std()))
+    torch.save(dict(unet_config=unet_cfg, x_T=x_T, context=cond["c_crossattn"][0], c_concat=cond["c_concat"][0], fs=fs, S=5, eta=1.0,
+                    seed=777, samples=samples), os.path.join(HERE, "ddim_eta_tiny.pt"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ddim_eta":
+        return ddim_eta_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "timesteps":
         return timestep_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "encode":

@@ -83,6 +83,22 @@ def test_ddim_sampler_matches_reference():
     assert e < 5e-5
 
 
+def test_stochastic_ddim_matches_reference():
+    """eta = 1 (sigma_t > 0, utils_diffusion.py:79-91; per-step torch.randn, ddim.py:271): the oracle loop, fed the same
+    seeded CPU noise stream, reproduces the reference sampler's output."""
+    g = load("ddim_eta_tiny.pt")
+    sd = seeded_state_dict(load("unet_tiny.pt")["shapes"])
+
+    def apply_model(x, t):
+        return ounet.unet_forward(sd, g["unet_config"], torch.cat([x, g["c_concat"]], 1), t, g["context"], g["fs"])
+    torch.manual_seed(g["seed"])
+    out = oddim.ddim_sample(apply_model, oddim.make_schedule(), oddim.make_scale_arr(), g["S"], g["x_T"], eta=g["eta"],
+                            noise_fn=lambda shape: torch.randn(shape))
+    e = rel(out, g["samples"])
+    print("ddim eta=1 oracle vs reference rel_l2", e)
+    assert e < 5e-5
+
+
 def test_vae_decode_matches_reference():
     g = load("vae_tiny.pt")
     sd = seeded_state_dict(g["shapes"])

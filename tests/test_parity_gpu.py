@@ -341,6 +341,34 @@ def test_plucker_cameras_vs_reference_golden(dev):
         raymap_to_camera_matrix(torch.zeros((1, 3, 2, 8, 11), device=dev), torch.zeros((1, 3, 2, 8, 11), device=dev))   # odd |H - W|
 
 
+def test_stochastic_ddim_matches_oracle_on_the_same_noise(dev):
+    """eta = 1: the sampler draws one torch.randn(size, device) per step exactly where the reference does (ddim.py:271), so the
+    device RNG stream can be recorded up front and replayed into the oracle loop (itself pinned to the reference at eta = 1 by
+    tests/golden/ddim_eta_tiny.pt): sigma_t, the sqrt(1 - a_prev - sigma_t^2) direction term and the noise term of the fused
+    update kernel are checked end to end."""
+    from geo4d_amd.ddim import DDIMSampler
+    g = load("ddim_eta_tiny.pt")
+    m, u, _ = _diffusion(dev, "f32")
+    size = tuple(g["x_T"].shape)
+    torch.manual_seed(4321)
+    recorded = [torch.randn(size, device=dev).cpu() for _ in range(g["S"])]
+    torch.manual_seed(4321)
+    cond = {"c_crossattn": [g["context"].to(dev)], "c_concat": [g["c_concat"].to(dev)]}
+    out, _ = DDIMSampler(m).sample(S=g["S"], conditioning=cond, batch_size=1, shape=list(size[1:]), verbose=False, eta=g["eta"],
+                                   unconditional_guidance_scale=1.0, unconditional_conditioning=None, fs=g["fs"].to(dev),
+                                   x_T=g["x_T"].to(dev), timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    usd = seeded_state_dict(u["shapes"])
+    it = iter(recorded)
+
+    def apply_model(x, t):
+        return ounet.unet_forward(usd, g["unet_config"], torch.cat([x, g["c_concat"]], 1), t, g["context"], g["fs"])
+    ref = oddim.ddim_sample(apply_model, oddim.make_schedule(), oddim.make_scale_arr(), g["S"], g["x_T"], eta=g["eta"],
+                            noise_fn=lambda shape: next(it))
+    e = rel(out, ref)
+    print(f"[ddim eta=1, replayed device noise] rel_l2 vs oracle = {e:.3e}")
+    assert e < 2e-4
+
+
 def test_stochastic_ddim_runs(dev):
     """eta > 0 draws torch noise per step (no hipGraph); RNG streams differ from the CPU reference, so only sanity here."""
     from geo4d_amd.ddim import DDIMSampler
