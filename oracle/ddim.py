@@ -71,3 +71,17 @@ def ddim_sample(apply_model, sched, scale_arr, S, x_T, eta=0.0, spacing="uniform
         noise = sigma_t * (noise_fn(x.shape) if (noise_fn is not None and eta > 0) else torch.zeros_like(x))
         x = a_prev.sqrt() * pred_x0 + dir_xt + noise
     return x
+
+
+def guided_output(e_c, e_u, scale, guidance_rescale=0.0, e_i=None, cfg_img=None):
+    """Classifier-free guidance as the reference samplers combine it: 2-way (ddim.py:216-229) or, with the image-yes /
+    text-"" evaluation e_i, 3-way (ddim_multiplecond.py:229-236); then rescale_noise_cfg (utils_diffusion.py:147-158)."""
+    if e_i is None:
+        out = e_u + scale * (e_c - e_u)
+    else:
+        out = e_u + (scale if cfg_img is None else cfg_img) * (e_i - e_u) + scale * (e_c - e_i)
+    if guidance_rescale > 0.0:
+        dims = list(range(1, out.ndim))
+        resc = out * (e_c.std(dim=dims, keepdim=True) / out.std(dim=dims, keepdim=True))
+        out = guidance_rescale * resc + (1 - guidance_rescale) * out
+    return out

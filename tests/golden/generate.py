@@ -239,7 +239,42 @@ def ddim_eta_fixtures():
                     seed=777, samples=samples), os.path.join(HERE, "ddim_eta_tiny.pt"))
 
 
+def ddim_cfg_fixtures():
+    """`python tests/golden/generate.py ddim_cfg` -> ddim_cfg_tiny.pt: the reference samplers with classifier-free guidance on:
+    lvdm.models.samplers.ddim.DDIMSampler (2-way, scale 7.5, guidance_rescale 0.7) and
+    lvdm.models.samplers.ddim_multiplecond.DDIMSampler (3-way, scale 7.5, cfg_img 2.0) on the tiny LatentDiffusion."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from lvdm.models.samplers.ddim import DDIMSampler
+    from lvdm.models.samplers.ddim_multiplecond import DDIMSampler as DDIMSamplerMulti
+
+    def cpu(cls):
+        class Cpu(cls):  # ddim.py:18-22 hard-codes torch.device("cuda")
+            def register_buffer(self, name, attr):
+                setattr(self, name, attr)
+        return Cpu
+    unet_cfg, dd, adp = tiny_configs()
+    model = build_reference(unet_cfg, dd, adp)
+    B, T, h, w = 1, 4, 8, 8
+    x_T = randn((B, 16, T, h, w), 600)
+    zc = randn((B, 4, T, h, w), 601)
+    ctx = [randn((B, 77 + 16 * T, unet_cfg["context_dim"]), 602 + i) for i in range(3)]      # cond, uncond, image-yes / text-""
+    mk = lambda c: {"c_crossattn": [c], "c_concat": [zc]}
+    fs = torch.tensor([24])
+    common = dict(S=3, conditioning=mk(ctx[0]), batch_size=B, shape=[16, T, h, w], verbose=False, eta=0.0, mask=None, x0=None, fs=fs,
+                  x_T=x_T, timestep_spacing="uniform_trailing", guidance_rescale=0.7, unconditional_guidance_scale=7.5,
+                  unconditional_conditioning=mk(ctx[1]))
+    with torch.no_grad():
+        two, _ = cpu(DDIMSampler)(model).sample(cfg_img=None, unconditional_conditioning_img_nonetext=None, **common)
+        three, _ = cpu(DDIMSamplerMulti)(model).sample(cfg_img=2.0, unconditional_conditioning_img_nonetext=mk(ctx[2]), **common)
+    print("cfg", float(two.std()), float(three.std()), float((two - three).abs().max()))
+    torch.save(dict(unet_config=unet_cfg, x_T=x_T, c_concat=zc, contexts=ctx, fs=fs, S=3, scale=7.5, cfg_img=2.0, guidance_rescale=0.7,
+                    samples_2way=two, samples_3way=three), os.path.join(HERE, "ddim_cfg_tiny.pt"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ddim_cfg":
+        return ddim_cfg_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "ddim_eta":
         return ddim_eta_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "timesteps":

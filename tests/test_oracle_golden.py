@@ -99,6 +99,23 @@ def test_stochastic_ddim_matches_reference():
     assert e < 5e-5
 
 
+def test_guided_ddim_matches_reference():
+    """Classifier-free guidance, 2-way (ddim.py) and 3-way (ddim_multiplecond.py), + guidance_rescale: the oracle loop with
+    oracle.ddim.guided_output vs outputs of the reference's two sampler classes."""
+    g = load("ddim_cfg_tiny.pt")
+    sd = seeded_state_dict(load("unet_tiny.pt")["shapes"])
+    ev = lambda x, t, c: ounet.unet_forward(sd, g["unet_config"], torch.cat([x, g["c_concat"]], 1), t, c, g["fs"])
+    c_c, c_u, c_i = g["contexts"]
+    two = oddim.ddim_sample(lambda x, t: oddim.guided_output(ev(x, t, c_c), ev(x, t, c_u), g["scale"], g["guidance_rescale"]),
+                            oddim.make_schedule(), oddim.make_scale_arr(), g["S"], g["x_T"], eta=0.0)
+    three = oddim.ddim_sample(lambda x, t: oddim.guided_output(ev(x, t, c_c), ev(x, t, c_u), g["scale"], g["guidance_rescale"],
+                                                                e_i=ev(x, t, c_i), cfg_img=g["cfg_img"]),
+                              oddim.make_schedule(), oddim.make_scale_arr(), g["S"], g["x_T"], eta=0.0)
+    e2, e3 = rel(two, g["samples_2way"]), rel(three, g["samples_3way"])
+    print("guided ddim oracle vs reference rel_l2", e2, e3)
+    assert e2 < 5e-5 and e3 < 5e-5
+
+
 def test_vae_decode_matches_reference():
     g = load("vae_tiny.pt")
     sd = seeded_state_dict(g["shapes"])

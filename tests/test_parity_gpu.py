@@ -341,6 +341,25 @@ def test_plucker_cameras_vs_reference_golden(dev):
         raymap_to_camera_matrix(torch.zeros((1, 3, 2, 8, 11), device=dev), torch.zeros((1, 3, 2, 8, 11), device=dev))   # odd |H - W|
 
 
+def test_guided_samplers_vs_reference_golden(dev):
+    """2-way (geo4d_amd.ddim) and 3-way (geo4d_amd.ddim_multiplecond) guidance + guidance_rescale vs outputs of the
+    reference's own lvdm.models.samplers.ddim / ddim_multiplecond classes on the same inputs (tests/golden/ddim_cfg_tiny.pt)."""
+    from geo4d_amd.ddim import DDIMSampler
+    from geo4d_amd.ddim_multiplecond import DDIMSampler as Multi
+    g = load("ddim_cfg_tiny.pt")
+    m, u, _ = _diffusion(dev, "f32")
+    mk = lambda c: {"c_crossattn": [c.to(dev)], "c_concat": [g["c_concat"].to(dev)]}
+    c_c, c_u, c_i = g["contexts"]
+    kw = dict(S=g["S"], conditioning=mk(c_c), batch_size=1, shape=list(g["x_T"].shape[1:]), verbose=False, eta=0.0,
+              unconditional_guidance_scale=g["scale"], unconditional_conditioning=mk(c_u), fs=g["fs"].to(dev), x_T=g["x_T"].to(dev),
+              timestep_spacing="uniform_trailing", guidance_rescale=g["guidance_rescale"])
+    two, _ = DDIMSampler(m).sample(cfg_img=None, unconditional_conditioning_img_nonetext=None, **kw)
+    three, _ = Multi(m).sample(cfg_img=g["cfg_img"], unconditional_conditioning_img_nonetext=mk(c_i), **kw)
+    e2, e3 = rel(two, g["samples_2way"]), rel(three, g["samples_3way"])
+    print(f"[guided samplers] 2-way {e2:.3e} 3-way {e3:.3e} vs reference")
+    assert e2 < 2e-4 and e3 < 2e-4
+
+
 def test_stochastic_ddim_matches_oracle_on_the_same_noise(dev):
     """eta = 1: the sampler draws one torch.randn(size, device) per step exactly where the reference does (ddim.py:271), so the
     device RNG stream can be recorded up front and replayed into the oracle loop (itself pinned to the reference at eta = 1 by
