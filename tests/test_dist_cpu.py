@@ -65,7 +65,8 @@ def _clip_worker(rank, world, port, q):
     gd.init_from_env(backend="gloo")
     video = torch.arange(1 * 3 * 22 * 16 * 16, dtype=torch.float32).reshape(1, 3, 22, 16, 16) / 1e4
     slices, maps = run_clip(_StubModel, video, torch.ones((1, 333, 8)), ddim_steps=2, synthesize=_stub_synth)
-    q.put((rank, [(s.start, s.stop) for s in slices], maps))
+    q.put((rank, [(s.start, s.stop) for s in slices], maps.numpy()))   # by value: a torch tensor would travel as a shared-memory fd
+                                                                      # served by this process, which may have exited before the parent reads it
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,7 +86,7 @@ def test_run_clip_world2_equals_world1():
     [p.join(timeout=60) for p in procs]
     for rank, sl, maps in res:
         assert sl == [(0, 16), (4, 20), (6, 22)]
-        assert torch.equal(maps, maps1), f"rank {rank}: sharded clip differs from the single-process clip"
+        assert torch.equal(torch.from_numpy(maps), maps1), f"rank {rank}: sharded clip differs from the single-process clip"
 
 
 def test_shard_tables():
