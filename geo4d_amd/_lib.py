@@ -82,6 +82,9 @@ SIGNATURES = {
                                      C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "geo4d_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                   C.c_void_p]),
+    "geo4d_cfg_combine_workspace": (C.c_size_t, [C.c_int]),
+    "geo4d_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_float,
+                                    C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "geo4d_advance_index": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_gather_timestep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_plucker_cameras_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

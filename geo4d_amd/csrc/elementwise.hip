@@ -165,6 +165,83 @@ extern "C" int geo4d_linear_small(const float* x, long ldx, const float* w, long
     return GEO4D_OK;
 }
 
+// ---- classifier-free guidance: combine 2 (or 3) U-Net outputs + rescale_noise_cfg ------------------------------------------
+// out = e_u + cfg_img (e_i - e_u) + scale (e_c - e_i)     (e_i == nullptr: out = e_u + scale (e_c - e_u))
+// pass 1 writes the combination and the per-sample sums of e_c, e_c^2, out, out^2 (fp64 partials per chunk, no atomics);
+// pass 2 (guidance_rescale > 0) merges the partials in a fixed order, forms the unbiased std ratio and blends in place.
+constexpr int CFG_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* __restrict__ ec, const float* __restrict__ eu, const float* __restrict__ ei,
+                                                          float* __restrict__ out, long n, float scale, float cfg_img, double* __restrict__ part) {
+    __shared__ double red[4][4];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const long per = (n + CFG_CHUNKS - 1) / CFG_CHUNKS;
+    const long i0 = (long)chunk * per, i1 = min(n, i0 + per);
+    const long base = (long)b * n;
+    double sc = 0.0, qc = 0.0, so = 0.0, qo = 0.0;
+    for (long i = i0 + tid; i < i1; i += 256) {
+        const float c = ec[base + i], u = eu[base + i];
+        float o;
+        if (ei) {
+            const float im = ei[base + i];
+            o = u + cfg_img * (im - u) + scale * (c - im);
+        } else {
+            o = u + scale * (c - u);
+        }
+        out[base + i] = o;
+        sc += c; qc += (double)c * c; so += o; qo += (double)o * o;
+    }
+    double v[4] = {sc, qc, so, qo};
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) x += __shfl_down(x, o2);
+        if (lane == 0) red[wave][k] = x;
+    }
+    __syncthreads();
+    if (tid < 4) part[((long)b * CFG_CHUNKS + chunk) * 4 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+__global__ __launch_bounds__(256) void cfg_rescale_kernel(float* __restrict__ out, long n, float rescale, const double* __restrict__ part) {
+    __shared__ float ratio_s;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid == 0) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < CFG_CHUNKS; ++c)
+            for (int k = 0; k < 4; ++k) s[k] += part[((long)b * CFG_CHUNKS + c) * 4 + k];
+        const double dn = (double)n;
+        const double var_c = (s[1] - s[0] * s[0] / dn) / (dn - 1.0), var_o = (s[3] - s[2] * s[2] / dn) / (dn - 1.0);   // torch.std: unbiased
+        ratio_s = (float)sqrt(var_c > 0.0 ? var_c : 0.0) / (float)sqrt(var_o > 0.0 ? var_o : 0.0);
+    }
+    __syncthreads();
+    const float ratio = ratio_s;
+    const long base = (long)b * n;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256) {
+        const float o = out[base + i];
+        out[base + i] = rescale * (o * ratio) + (1.0f - rescale) * o;
+    }
+}
+
+extern "C" size_t geo4d_cfg_combine_workspace(int B) { return (size_t)B * CFG_CHUNKS * 4 * sizeof(double); }
+
+extern "C" int geo4d_cfg_combine(const float* e_c, const float* e_u, const float* e_i, float* out, int B, long n, float scale, float cfg_img,
+                                 float guidance_rescale, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e_c || !e_u || !out || B <= 0 || B > 65535 || n <= 1) { geo4d_set_error("cfg_combine: bad arguments"); return GEO4D_EINVAL; }
+    if (!workspace || workspace_bytes < geo4d_cfg_combine_workspace(B) || ((uintptr_t)workspace & 7)) { geo4d_set_error("cfg_combine: workspace too small / unaligned"); return GEO4D_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(CFG_CHUNKS, B), dim3(256), 0, s, e_c, e_u, e_i, out, n, scale, cfg_img, (double*)workspace);
+    GEO4D_CHECK_LAUNCH();
+    if (guidance_rescale > 0.f) {
+        long blocks = (n + 255) / 256;
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(cfg_rescale_kernel, dim3((unsigned)blocks, B), dim3(256), 0, s, out, n, guidance_rescale, (const double*)workspace);
+        GEO4D_CHECK_LAUNCH();
+    }
+    return GEO4D_OK;
+}
+
 extern "C" int geo4d_ddim_step(float* x, const float* v, const float* noise, float* pred_x0, const float* coef, const int* step_index,
                                long n, void* stream) {
     if (!x || !v || !coef || !step_index || n <= 0) { geo4d_set_error("ddim_step: bad arguments"); return GEO4D_EINVAL; }

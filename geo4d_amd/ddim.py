@@ -120,16 +120,11 @@ class DDIMSampler(object):
                 return self.model.apply_model(img, ts, conditioning, fs=fs, **kwargs)
             e_c = self.model.apply_model(img, ts, conditioning, fs=fs, **kwargs)
             e_u = self.model.apply_model(img, ts, unconditional_conditioning, fs=fs, **kwargs)
-            if uc_img is not None:
-                e_i = self.model.apply_model(img, ts, uc_img, fs=fs, **kwargs)
-                out = e_u + cfg_img * (e_i - e_u) + unconditional_guidance_scale * (e_c - e_i)
-            else:
-                out = e_u + unconditional_guidance_scale * (e_c - e_u)
-            if guidance_rescale > 0.0:                                          # utils_diffusion.py:147-158
-                dims = list(range(1, out.ndim))
-                resc = out * (e_c.std(dim=dims, keepdim=True) / out.std(dim=dims, keepdim=True))
-                out = guidance_rescale * resc + (1 - guidance_rescale) * out
-            return out
+            e_i = self.model.apply_model(img, ts, uc_img, fs=fs, **kwargs) if uc_img is not None else None
+            # ddim.py:216-229 / ddim_multiplecond.py:229-236 + rescale_noise_cfg (utils_diffusion.py:147-158): one fused HIP op
+            f = lambda t: None if t is None else t.float().contiguous()
+            return ops.cfg_combine(f(e_c), f(e_u), f(e_i), scale=unconditional_guidance_scale, cfg_img=cfg_img,
+                                   guidance_rescale=guidance_rescale)
 
         def step(noise=None):
             ops.gather_timestep(idx, self.ts_table, ts)

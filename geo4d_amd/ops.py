@@ -381,6 +381,23 @@ def ddim_step(x, v, coef, step_index, noise=None, pred_x0=None):
     return x
 
 
+def cfg_combine(e_c, e_u, e_i=None, *, scale, cfg_img=None, guidance_rescale=0.0):
+    """Classifier-free guidance on fp32 U-Net outputs [B, ...]: 2-way, or 3-way with e_i (image yes / text ""), + rescale_noise_cfg."""
+    lib = _lib.load()
+    _dev(e_c, "e_c")
+    ts = [t for t in (e_c, e_u, e_i) if t is not None]
+    assert all(t.dtype == torch.float32 and t.is_contiguous() and t.shape == e_c.shape for t in ts)
+    B = e_c.shape[0]
+    n = e_c.numel() // B
+    out = torch.empty_like(e_c)
+    need = lib.geo4d_cfg_combine_workspace(B)
+    ws = torch.empty(need // 8, device=e_c.device, dtype=torch.float64)
+    _lib.check(lib.geo4d_cfg_combine(e_c.data_ptr(), e_u.data_ptr(), _ptr(e_i), out.data_ptr(), B, n, float(scale),
+                                     float(scale if cfg_img is None else cfg_img), float(guidance_rescale), ws.data_ptr(), need,
+                                     _stream()), "geo4d_cfg_combine")
+    return out
+
+
 def advance_index(idx, delta):
     lib = _lib.load()
     _lib.check(lib.geo4d_advance_index(idx.data_ptr(), delta, _stream()), "geo4d_advance_index")

@@ -132,6 +132,14 @@ int geo4d_linear_small(const float* x, long ldx, const float* w, long ldw, const
  * replaces DDIMSampler.p_sample_ddim arithmetic (ddim.py:232-277) + DDPM.predict_* (ddpm3d.py:278-290). */
 int geo4d_ddim_step(float* x, const float* v, const float* noise, float* pred_x0, const float* coef, const int* step_index,
                     long n, void* stream);
+/* Classifier-free guidance on fp32 [B][n] U-Net outputs:
+ *   out = e_u + cfg_img (e_i - e_u) + scale (e_c - e_i)          (e_i == NULL: out = e_u + scale (e_c - e_u))
+ *   guidance_rescale > 0: out = r * out * std(e_c)/std(out) + (1 - r) * out, unbiased std per batch sample over the n other elements
+ * replaces the combination in DDIMSampler.p_sample_ddim (ddim.py:216-229; 3-way: ddim_multiplecond.py:229-236) and
+ * rescale_noise_cfg (utils_diffusion.py:147-158). workspace: geo4d_cfg_combine_workspace(B) bytes, 8-byte aligned. */
+size_t geo4d_cfg_combine_workspace(int B);
+int geo4d_cfg_combine(const float* e_c, const float* e_u, const float* e_i, float* out, int B, long n, float scale, float cfg_img,
+                      float guidance_rescale, void* workspace, size_t workspace_bytes, void* stream);
 int geo4d_advance_index(int* idx, int delta, void* stream);
 /* ts[b] = table[*idx] for b < B: the per-step `ts = torch.full((b,), step)` of ddim.py:170, read from a device table so
  * the captured step graph is step-independent. */

@@ -321,6 +321,25 @@ def test_embedding_and_small_linear(dev):
     check("linear_small", out, TF.silu(TF.silu(e) @ w.t() + b) + add, torch.float32)
 
 
+@pytest.mark.parametrize("three_way", [False, True])
+@pytest.mark.parametrize("rescale", [0.0, 0.7])
+def test_cfg_combine(dev, three_way, rescale):
+    """geo4d_cfg_combine vs the reference formulas (ddim.py:216-229, ddim_multiplecond.py:229-236, utils_diffusion.py:147-158)."""
+    from geo4d_amd import ops
+    g = torch.Generator().manual_seed(11)
+    shape = (2, 16, 5, 7, 9)                     # n = 5040 per sample: not a multiple of the chunking
+    e_c, e_u, e_i = (torch.randn(shape, generator=g).to(dev) * (1.0 + k) + 0.1 * k for k in range(3))
+    got = ops.cfg_combine(e_c, e_u, e_i if three_way else None, scale=7.5, cfg_img=2.0 if three_way else None, guidance_rescale=rescale)
+    ref = e_u + 2.0 * (e_i - e_u) + 7.5 * (e_c - e_i) if three_way else e_u + 7.5 * (e_c - e_u)
+    if rescale > 0:
+        dims = list(range(1, ref.ndim))
+        r = ref * (e_c.std(dim=dims, keepdim=True) / ref.std(dim=dims, keepdim=True))
+        ref = rescale * r + (1 - rescale) * ref
+    err = ((got - ref).norm() / ref.norm()).item()
+    print(f"[cfg_combine three_way={three_way} rescale={rescale}] rel_l2={err:.2e}")
+    assert got.shape == ref.shape and err < 2e-6
+
+
 def test_ddim_step(dev):
     from geo4d_amd import ops
     x, v, nz = rnd((1000,), dev, torch.float32, 47), rnd((1000,), dev, torch.float32, 48), rnd((1000,), dev, torch.float32, 49)
