@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Launch the level-0 self-attention shape N times (for rocprofv3 --pmc passes over flash_attn_kernel). usage: pmc_attn.py [iters]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geo4d_amd import ops
