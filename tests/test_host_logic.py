@@ -152,3 +152,47 @@ def test_tuning_table_uses_only_known_tile_hints():
         assert split in (0, 1, 2, 4, 8, 16), (key, split)
         assert re.match(r"^\d/\d\|\d+x\d+x\d+\|c\d+\|t\d{3}s\du\d\|a\dr\dn\d\|b\d+$", key), key
     assert all(t in documented for t, _ in ops._CANDIDATES)
+
+
+def test_weight_relayout_is_the_same_linear_map():
+    """geo4d_amd/pack.py (host logic, runs once per load): the packed matrices, applied as the kernel applies them
+    (out[m][n] = sum_k A_gather[m][k] W[n][k], taps outer / channels inner, padded channels zero), reproduce F.conv2d,
+    F.conv3d (3,1,1), F.linear and GEGLU (attention.py:415-422) on CPU."""
+    import torch.nn.functional as F
+    from geo4d_amd import pack
+    g = torch.Generator().manual_seed(3)
+    dt = torch.float32
+    # conv2d 3x3, Cin = 5 padded to the f32 K alignment
+    x = torch.randn((2, 5, 6, 7), generator=g)
+    w = torch.randn((4, 5, 3, 3), generator=g)
+    wp = pack.pack_conv2d(w, dt)
+    cp = wp.shape[1] // 9
+    assert cp >= 5 and cp % 4 == 0                                                # f32: padded to one 32-element K slab
+    cols = F.unfold(F.pad(x, (0, 0, 0, 0, 0, cp - 5)), 3, padding=1)             # [2, cp*9, 42], channel-major / tap-minor
+    cols = cols.reshape(2, cp, 9, 42).permute(0, 3, 2, 1).reshape(2 * 42, 9 * cp)  # rows = pixels, K = tap-major / channel-minor
+    assert torch.allclose((cols @ wp.t()).reshape(2, 6, 7, 4).permute(0, 3, 1, 2), F.conv2d(x, w, padding=1), atol=1e-5)
+    # temporal conv (3,1,1)
+    xt = torch.randn((1, 8, 5, 2, 3), generator=g)
+    wt = torch.randn((6, 8, 3, 1, 1), generator=g)
+    wtp = pack.pack_conv3d_t(wt, dt)
+    xp = F.pad(xt, (0, 0, 0, 0, 1, 1))
+    rows = torch.stack([xp[:, :, k:k + 5] for k in range(3)], dim=1)              # [1, tap, C, T, h, w]
+    rows = rows.permute(0, 3, 4, 5, 1, 2).reshape(-1, 3 * 8)
+    assert torch.allclose((rows @ wtp.t()).reshape(1, 5, 2, 3, 6).permute(0, 4, 1, 2, 3), F.conv3d(xt, wt, padding=(1, 0, 0)), atol=1e-5)
+    # linear with K padding
+    wl = torch.randn((7, 10), generator=g)
+    wlp = pack.pack_linear(wl, dt)
+    xl = torch.randn((3, 10), generator=g)
+    assert wlp.shape[1] % 4 == 0 and torch.allclose(F.pad(xl, (0, wlp.shape[1] - 10)) @ wlp.t(), xl @ wl.t(), atol=1e-6)
+    # GEGLU: value / gate rows interleaved in blocks of 32 -> out[:, 32j + i] = value * gelu(gate) of column 32j + i
+    inner = 64
+    wg, bg = torch.randn((2 * inner, 12), generator=g), torch.randn((2 * inner,), generator=g)
+    wgp, bgp = pack.pack_geglu(wg, bg, dt)
+    xg = torch.randn((5, 12), generator=g)
+    h = F.pad(xg, (0, wgp.shape[1] - 12)) @ wgp.t() + bgp
+    blocks = h.reshape(5, inner // 32, 2, 32)
+    got = (blocks[:, :, 0] * F.gelu(blocks[:, :, 1])).reshape(5, inner)
+    ref = xg @ wg.t() + bg
+    assert torch.allclose(got, ref[:, :inner] * F.gelu(ref[:, inner:]), atol=1e-5)
+    perm = pack.geglu_perm(inner)
+    assert sorted(perm.tolist()) == list(range(2 * inner))
