@@ -12,6 +12,15 @@ reads the committed .pt files. What is imported from the reference, unmodified:
 Missing third-party modules are stubbed: cv2 (unused on this path), pytorch_lightning.LightningModule -> nn.Module,
 torchvision.utils.make_grid (logging only). Weights: oracle.params (name-keyed seeded fill), so fixtures hold only
 inputs and outputs.
+
+Modes (each writes its own file and leaves the others untouched):
+  (no argument)  schedule.pt, unet_tiny.pt, unet_full.pt, vae_tiny.pt, ddim_tiny.pt, glue.pt   - the §8(a)-(e) path
+  encode         vae_encode_tiny.pt   AutoencoderKL.encode / encode_with_adaptor, LatentDiffusion.encode_first_stage (seeded)
+  rays           rays.pt              raymap_to_camera_matrix -> utils/rays.py cameras_from_plucker (pytorch3d's PerspectiveCameras
+                                      stubbed as a plain container of R / T / focal_length)
+  timesteps      timesteps.pt         make_ddim_timesteps for every spacing method x 16 step counts
+  ddim_eta       ddim_eta_tiny.pt     DDIMSampler at eta = 1 with a seeded CPU noise stream
+  ddim_cfg       ddim_cfg_tiny.pt     2-way (ddim.py) and 3-way (ddim_multiplecond.py) classifier-free guidance + guidance_rescale
 """
 import ast
 import os
