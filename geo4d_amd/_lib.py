@@ -12,9 +12,9 @@ import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its o
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 
 
 class Geo4DNativeError(RuntimeError):
@@ -36,6 +36,7 @@ class ConvGemm(C.Structure):
         ("rowbias_div", C.c_int), ("bias_per_row", C.c_int), ("act", C.c_int),
         ("dtype", C.c_int), ("out_dtype", C.c_int), ("out_nchw", C.c_int), ("tile_hint", C.c_int),
         ("split_k", C.c_int), ("debug_ablate", C.c_int), ("alpha", C.c_float),
+        ("a_split", C.c_int), ("w_split", C.c_int),
     ]
 
 
@@ -60,7 +61,7 @@ class Attention(C.Structure):
     ]
 
 
-# name -> (restype, argtypes); this table is checked against include/geo4d_hip.h by tests/test_abi.py
+# name -> (restype, argtypes); checked against include/geo4d_hip.h by tests/test_host_logic.py::test_c_abi_exports_every_declared_symbol
 SIGNATURES = {
     "geo4d_conv_gemm": (C.c_int, [C.POINTER(ConvGemm), C.c_void_p]),
     "geo4d_groupnorm_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
     constexpr int TILE = 64 * ROWB;               // one operand tile
     constexpr int NDMA = TILE / 1024 / 4;         // DMA instructions per wave per operand: 2 / 4
     constexpr int RPI = 1024 / ROWB;              // rows per DMA instruction: 8 / 4
-    constexpr int PCH = 16 / EPC;                 // P chunks per 32-key block
+    constexpr int PCH = IsX3<T>::value ? 2 : 16 / EPC;   // P chunks per 32-key block (x3: 16 keys per bf16 MFMA step, like the 16-bit types)
     __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];   // [buf][K | Vt]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,14 +45,29 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
     const bool qok = qrow < p.Nq;
     const T* __restrict__ Z = (const T*)p.zeros;
 
-    u32x4 qf[NKK];
+    constexpr bool X3 = IsX3<T>::value;        // f32 storage, bf16 hi/lo split in registers, 3 bf16 MFMAs per product
+    constexpr int NQ = X3 ? 4 : NKK;              // MFMA k-steps over d = 64 (16 per step for the bf16 MFMA of the x3 path)
+    u32x4 qf[NQ], ql[X3 ? 4 : 1];                 // x3: qf = hi parts, ql = lo parts
     {
         const T* qp = (const T*)p.q + ((long)b * p.Nq + (qok ? qrow : 0)) * p.ldq + h * 64;
+        if constexpr (X3) {
+            // k-step s2 covers d = 16 s2 .. +16; lane (li, g) owns d = 16 s2 + 8 g .. +8 = f32 chunks 4 s2 + 2 g, + 1
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (qok) v = *(const u32x4*)(qp + (2 * kk + g) * EPC);
-            qf[kk] = v;
+            for (int s2 = 0; s2 < 4; ++s2) {
+                u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
+                if (qok) {
+                    c0 = *(const u32x4*)(qp + (4 * s2 + 2 * g) * EPC);
+                    c1 = *(const u32x4*)(qp + (4 * s2 + 2 * g + 1) * EPC);
+                }
+                split8_bf16(c0, c1, qf[s2], ql[s2]);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (qok) v = *(const u32x4*)(qp + (2 * kk + g) * EPC);
+                qf[kk] = v;
+            }
         }
     }
     f32x16 of[NSEG == 1 ? 1 : 2], oa[2];        // `of` (sum over segments) only exists for the dual-KV cross attention
@@ -141,10 +156,22 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            if constexpr (X3) {
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const u32x4 a = *(const u32x4*)(ktile + (kb * 32 + li) * ROWB + (((2 * kk + g) ^ swz) << 4));
-                cmma<T>(st[kb], a, qf[kk]);
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const char* krow_ = ktile + (kb * 32 + li) * ROWB;
+                    const u32x4 c0 = *(const u32x4*)(krow_ + (((4 * s2 + 2 * g) ^ swz) << 4));
+                    const u32x4 c1 = *(const u32x4*)(krow_ + (((4 * s2 + 2 * g + 1) ^ swz) << 4));
+                    u32x4 kh, kl;
+                    split8_bf16(c0, c1, kh, kl);
+                    mma_x3(st[kb], kh, kl, qf[s2], ql[s2]);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const u32x4 a = *(const u32x4*)(ktile + (kb * 32 + li) * ROWB + (((2 * kk + g) ^ swz) << 4));
+                    cmma<T>(st[kb], a, qf[kk]);
+                }
             }
         }
         // ---- online softmax on raw scores; exp2 with the scale folded in ----------------------
@@ -195,24 +222,43 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int c = 0; c < PCH; ++c) {
-                float pv[EPC];
+                if constexpr (X3) {
+                    // P registers 8c .. 8c+7 of this lane = keys 32 kb + 16 c + 4 g + {0..3} and + 8 (see acc_row): split them once,
+                    // fetch the same keys of V^T (f32 chunks 8 kb + 4 c + g and + 2) per 32-channel block and split those
+                    float pv[8];
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) pv[j] = st[kb][c * EPC + j];
-                const u32x4 bch = f32_to_chunk<T>(pv);
+                    for (int j = 0; j < 8; ++j) pv[j] = st[kb][c * 8 + j];
+                    u32x4 ph, pl;
+                    split8_bf16(pv, ph, pl);
 #pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    u32x4 a;
-                    const char* vrow = vtile + (d * 32 + li) * ROWB;
-                    if constexpr (ES == 2) {
-                        // keys kb*32 + 16c + 4g + {0..3} and +8: byte offset 64kb + 32c + 8g (+16): slots 4kb + 2c (+1), half g
-                        const u32x2 lo = *(const u32x2*)(vrow + (((4 * kb + 2 * c) ^ swz) << 4) + 8 * g);
-                        const u32x2 hi = *(const u32x2*)(vrow + (((4 * kb + 2 * c + 1) ^ swz) << 4) + 8 * g);
-                        a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
-                    } else {
-                        // keys kb*32 + 8c + 4g + {0..3}: slot 8kb + 2c + g
-                        a = *(const u32x4*)(vrow + (((8 * kb + 2 * c + g) ^ swz) << 4));
+                    for (int d = 0; d < 2; ++d) {
+                        const char* vrow = vtile + (d * 32 + li) * ROWB;
+                        const u32x4 c0 = *(const u32x4*)(vrow + (((8 * kb + 4 * c + g) ^ swz) << 4));
+                        const u32x4 c1 = *(const u32x4*)(vrow + (((8 * kb + 4 * c + 2 + g) ^ swz) << 4));
+                        u32x4 vh, vl;
+                        split8_bf16(c0, c1, vh, vl);
+                        mma_x3(oa[d], vh, vl, ph, pl);
                     }
-                    cmma<T>(oa[d], a, bch);
+                } else {
+                    float pv[EPC];
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) pv[j] = st[kb][c * EPC + j];
+                    const u32x4 bch = f32_to_chunk<T>(pv);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        u32x4 a;
+                        const char* vrow = vtile + (d * 32 + li) * ROWB;
+                        if constexpr (ES == 2) {
+                            // keys kb*32 + 16c + 4g + {0..3} and +8: byte offset 64kb + 32c + 8g (+16): slots 4kb + 2c (+1), half g
+                            const u32x2 lo = *(const u32x2*)(vrow + (((4 * kb + 2 * c) ^ swz) << 4) + 8 * g);
+                            const u32x2 hi = *(const u32x2*)(vrow + (((4 * kb + 2 * c + 1) ^ swz) << 4) + 8 * g);
+                            a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
+                        } else {
+                            // keys kb*32 + 8c + 4g + {0..3}: slot 8kb + 2c + g
+                            a = *(const u32x4*)(vrow + (((8 * kb + 2 * c + g) ^ swz) << 4));
+                        }
+                        cmma<T>(oa[d], a, bch);
+                    }
                 }
             }
         // ---- segment end: normalise and fold into the summed output ---------------------------
@@ -365,8 +411,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
 extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     if (!pp) return GEO4D_EINVAL;
     const geo4d_attention_t& p = *pp;
-    const int esz = p.dtype == GEO4D_F32 ? 4 : 2;
-    if (p.dtype < 0 || p.dtype > 2 || p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.nseg < 1 || p.nseg > 2) { geo4d_set_error("attention: bad arguments"); return GEO4D_EINVAL; }
+    const int esz = (p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3) ? 4 : 2;
+    if (p.dtype < 0 || p.dtype > 3 || p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.nseg < 1 || p.nseg > 2) { geo4d_set_error("attention: bad arguments"); return GEO4D_EINVAL; }
     if (p.head_dim != 64) { geo4d_set_error("attention: only d_head = 64 is built (yaml num_head_channels: 64)"); return GEO4D_ENOTSUP; }
     if ((p.ldq * esz) % 16 || (p.ldo * esz) % 16 || ((uintptr_t)p.q % 16) || ((uintptr_t)p.o % 16)) { geo4d_set_error("attention: q/o alignment"); return GEO4D_EINVAL; }
     for (int s = 0; s < p.nseg; ++s) {
@@ -384,12 +430,14 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
         switch (p.dtype) {
             case GEO4D_F32: hipLaunchKernelGGL((flash_attn_kernel<float, 1>), grid, dim3(256), 0, st, p); break;
             case GEO4D_BF16: hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, p); break;
+            case GEO4D_BF16X3: hipLaunchKernelGGL((flash_attn_kernel<bf16x3_t, 1>), grid, dim3(256), 0, st, p); break;
             default: hipLaunchKernelGGL((flash_attn_kernel<f16_t, 1>), grid, dim3(256), 0, st, p); break;
         }
     } else {
         switch (p.dtype) {
             case GEO4D_F32: hipLaunchKernelGGL((flash_attn_kernel<float, 2>), grid, dim3(256), 0, st, p); break;
             case GEO4D_BF16: hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 2>), grid, dim3(256), 0, st, p); break;
+            case GEO4D_BF16X3: hipLaunchKernelGGL((flash_attn_kernel<bf16x3_t, 2>), grid, dim3(256), 0, st, p); break;
             default: hipLaunchKernelGGL((flash_attn_kernel<f16_t, 2>), grid, dim3(256), 0, st, p); break;
         }
     }

@@ -20,6 +20,7 @@
 #define GEO4D_F32 0
 #define GEO4D_BF16 1
 #define GEO4D_F16 2
+#define GEO4D_BF16X3 3   // f32 STORAGE, bf16 MFMA on a 3-term hi/lo split (x_hi.w_hi + x_hi.w_lo + x_lo.w_hi): ~16-bit mantissas
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -33,6 +34,11 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 struct bf16_t { unsigned short v; };
 struct f16_t { unsigned short v; };
+// "bf16x3": an operand element occupies 4 bytes like an f32. Activations ARE plain f32 in memory (every non-GEMM kernel
+// runs its f32 instantiation on them) and are split into bf16 hi + bf16 lo in registers right before the MFMA; weights are
+// split once at pack time and stored per 8 K-elements as [8 x bf16 hi | 8 x bf16 lo] (two 16-byte chunks = the same 32 bytes
+// 8 f32 would take), so a fragment read is the same two ds_read_b128 for both layouts.
+struct bf16x3_t { float v; };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
@@ -77,6 +83,14 @@ template <> struct Elem<f16_t> {
     __device__ static __forceinline__ float ld(const f16_t* p) { return f16_bits_to_f32(p->v); }
     __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f32_to_f16_bits(v); }
 };
+template <> struct Elem<bf16x3_t> {
+    static constexpr int EPC = 4;      // storage granularity is f32: 4 elements per 16-byte chunk
+    static constexpr int DT = GEO4D_BF16X3;
+    __device__ static __forceinline__ float ld(const bf16x3_t* p) { return p->v; }
+    __device__ static __forceinline__ void st(bf16x3_t* p, float v) { p->v = v; }
+};
+template <typename T> struct IsX3 { static constexpr bool value = false; };
+template <> struct IsX3<bf16x3_t> { static constexpr bool value = true; };
 
 // ---- chunk <-> float conversion -----------------------------------------------------------
 template <typename T> __device__ __forceinline__ void chunk_to_f32(const u32x4& c, float* out);
@@ -99,7 +113,17 @@ template <> __device__ __forceinline__ void chunk_to_f32<f16_t>(const u32x4& c, 
     }
 }
 template <typename T> __device__ __forceinline__ u32x4 f32_to_chunk(const float* in);
+template <> __device__ __forceinline__ void chunk_to_f32<bf16x3_t>(const u32x4& c, float* out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = __uint_as_float(c[j]);
+}
 template <> __device__ __forceinline__ u32x4 f32_to_chunk<float>(const float* in) {
+    u32x4 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = __float_as_uint(in[j]);
+    return c;
+}
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<bf16x3_t>(const float* in) {
     u32x4 c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) c[j] = __float_as_uint(in[j]);
@@ -131,6 +155,27 @@ template <> __device__ __forceinline__ void cmma<float>(f32x16& acc, const u32x4
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+}
+// ---- bf16x3: 8 f32 -> 8 bf16 hi + 8 bf16 lo (x ~ hi + lo to ~16 mantissa bits), and the 3-term product ----------------
+// element 2j sits in the low half of word j (the order v_cvt_pk_bf16_f32 packs and the order pack.py writes split weights)
+__device__ __forceinline__ void split8_bf16(const float* x, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int h = f32x2_to_bf16x2(x[2 * j], x[2 * j + 1]);
+        hi[j] = h;
+        lo[j] = f32x2_to_bf16x2(x[2 * j] - __uint_as_float(h << 16), x[2 * j + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
+__device__ __forceinline__ void split8_bf16(const u32x4& c0, const u32x4& c1, u32x4& hi, u32x4& lo) {
+    const float x[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                        __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+    split8_bf16(x, hi, lo);
+}
+// acc += a.b with a = ah + al, b = bh + bl, dropping al.bl (2^-16 x 2^-16): three dense bf16 MFMAs, fp32 accumulate
+__device__ __forceinline__ void mma_x3(f32x16& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
 }
 // row index inside a 32x32 accumulator block for register r on half-wave hi
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -7,6 +7,10 @@
 //                                      folded into the gather (src = dst >> 1), nothing is materialised
 //   nn.Conv3d (3,1,1), pad (1,0,0)    (openaimodel3d.py:257-266 TemporalConvBlock) — 3 temporal taps
 //   batched Q.K^T / P.V GEMMs         (ae_modules.py:53-78 VAE AttnBlock, d = 512)
+// Element types: bf16 / f16 (one MFMA 32x32x16 per 16 k), f32 (exact, v_mfma_f32_32x32x2_f32) and bf16x3 — f32 in memory,
+// split into bf16 hi + lo in registers (weights pre-split at pack time) and multiplied with three bf16 MFMAs per 16 k: the
+// precision of ~16-bit mantissas (point-map parity 1e-3 needs more than any single 16-bit pass gives, tests/precision_sim.py)
+// at 3/16 of the f32-MFMA cost.
 // Activations are channels-last tokens [F, H*W, C]; weights are packed [N][taps*Cin] (K-major, tap-major).
 // out[m][n] = epilogue(alpha * sum_k A_gather[m][k] * W[n][k])
 //
@@ -37,6 +41,7 @@ namespace geo4d_gemm {
 extern template int launch_typed<float>(const geo4d_conv_gemm_t&, hipStream_t);
 extern template int launch_typed<bf16_t>(const geo4d_conv_gemm_t&, hipStream_t);
 extern template int launch_typed<f16_t>(const geo4d_conv_gemm_t&, hipStream_t);
+extern template int launch_typed<bf16x3_t>(const geo4d_conv_gemm_t&, hipStream_t);
 }  // namespace geo4d_gemm
 using geo4d_gemm::BKC;
 using geo4d_gemm::MAXTAP;
@@ -45,10 +50,12 @@ using geo4d_gemm::launch_typed;
 extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     if (!pp) return GEO4D_EINVAL;
     geo4d_conv_gemm_t p = *pp;
-    const int esz = p.dtype == GEO4D_F32 ? 4 : 2;
+    const int esz = (p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3) ? 4 : 2;
     const int epc = 16 / esz;
     const int bk = BKC * epc;
-    if (p.dtype < 0 || p.dtype > 2 || p.out_dtype < 0 || p.out_dtype > 2) { geo4d_set_error("conv_gemm: bad dtype"); return GEO4D_EINVAL; }
+    if (p.dtype < 0 || p.dtype > 3 || p.out_dtype < 0 || p.out_dtype > 2) { geo4d_set_error("conv_gemm: bad dtype"); return GEO4D_EINVAL; }
+    if (p.dtype != GEO4D_BF16X3 && (p.a_split || p.w_split)) { geo4d_set_error("conv_gemm: a_split / w_split are bf16x3 (dtype 3) options"); return GEO4D_EINVAL; }
+    if (p.a_split && p.KT * p.KH * p.KW != 1) { geo4d_set_error("conv_gemm: a pre-split A operand must be a plain matrix (1 tap)"); return GEO4D_EINVAL; }
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) { geo4d_set_error("conv_gemm: empty problem"); return GEO4D_EINVAL; }
     if (p.KT <= 0 || p.KH <= 0 || p.KW <= 0 || p.KT * p.KH * p.KW > MAXTAP) { geo4d_set_error("conv_gemm: at most 9 taps"); return GEO4D_EINVAL; }
     if (p.Cin % bk || p.K != p.Cin * p.KT * p.KH * p.KW) { geo4d_set_error("conv_gemm: Cin must be a multiple of the 128-byte K slab and K = taps*Cin"); return GEO4D_EINVAL; }
@@ -69,6 +76,7 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     switch (p.dtype) {
         case GEO4D_F32: return launch_typed<float>(p, s);
         case GEO4D_BF16: return launch_typed<bf16_t>(p, s);
+        case GEO4D_BF16X3: return launch_typed<bf16x3_t>(p, s);
         default: return launch_typed<f16_t>(p, s);
     }
 }

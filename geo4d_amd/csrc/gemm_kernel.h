@@ -66,7 +66,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     const int hw = p.Hout * p.Wout;
 
     // ---- gather table: source pixel index of (tile row, tap), -1 where the tap falls into padding ------
-    {
+    // Plain linears / batched GEMMs (1 tap, no stride / upsample, same pixel count in and out: source row == output row) skip
+    // the table, its integer divides and its barrier: their rows are resolved straight into registers below.
+    const bool direct_rows = ntap == 1 && p.stride == 1 && p.ups == 1 && p.ph == 0 && p.pw == 0 && p.pt == 0 &&
+                             p.Hin * p.Win == hw;
+    if (!direct_rows) {
         const int hlim = p.ups == 2 ? 2 * p.Hin : p.Hin, wlim = p.ups == 2 ? 2 * p.Win : p.Win;
         const int ush = p.ups == 2 ? 1 : 0;
         for (int e = tid; e < BM * ntap; e += NT) {
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
             }
             rowpix[e] = pix;
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     const int ccol = tid & 7;
     const int r0 = tid >> 3;
@@ -118,6 +122,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     int tap = s_begin % ntap;
     int c0 = (s_begin / ntap) * BK;
     auto fetch_pix = [&]() {
+        if (direct_rows) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int m = tm * BM + r0 + i * RSTEP;
+                pix[i] = m < p.M ? m : -1;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ACH; ++i) pix[i] = rowpix[(r0 + i * RSTEP) * ntap + tap];
     };
@@ -163,10 +175,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     // one K slab of MFMAs out of ring buffer `buf`. Small wave tiles double-buffer their fragments in registers (the ds_reads
     // of step kk+1 are in flight under the MFMAs of step kk); the 64x128 wave tile of the 256x256 configuration has no VGPRs
     // to spare for that and relies on its second wave per SIMD instead.
+    // bf16x3: a 128-byte slab holds 32 K-elements = two MFMA k-steps of 16; lane (li, g) owns elements 16s + 8g .. +8 of its
+    // row = chunks 4s + 2g and 4s + 2g + 1 (raw f32 -> split in registers; pre-split weights: chunk 0 = hi, chunk 1 = lo)
+    int foffx[2][2];
+    if constexpr (IsX3<T>::value) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) foffx[s2][j] = li * PITCH + (((4 * s2 + 2 * g + j) ^ ((li >> 1) & 7)) << 4);
+    }
+    const bool a_split = p.a_split != 0, w_split = p.w_split != 0;
     auto compute_slab = [&](int buf) {
         const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
         const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
-        if constexpr (MB * NB <= 4) {
+        if constexpr (IsX3<T>::value) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+                for (int a = 0; a < MB; ++a) {
+                    const u32x4 c0 = *(const u32x4*)(abase + a * 32 * PITCH + foffx[s2][0]);
+                    const u32x4 c1 = *(const u32x4*)(abase + a * 32 * PITCH + foffx[s2][1]);
+                    if (a_split) { ah[a] = c0; al[a] = c1; }
+                    else split8_bf16(c0, c1, ah[a], al[a]);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const u32x4 c0 = *(const u32x4*)(bbase + b * 32 * PITCH + foffx[s2][0]);
+                    const u32x4 c1 = *(const u32x4*)(bbase + b * 32 * PITCH + foffx[s2][1]);
+                    if (w_split) { bh[b] = c0; bl[b] = c1; }
+                    else split8_bf16(c0, c1, bh[b], bl[b]);
+                }
+#pragma unroll
+                for (int a = 0; a < MB; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) mma_x3(acc[a][b], bh[b], bl[b], ah[a], al[a]);   // C rows = n, C cols = m
+            }
+        } else if constexpr (MB * NB <= 4) {
             u32x4 fa[2][MB], fb[2][NB];
 #pragma unroll
             for (int a = 0; a < MB; ++a) fa[0][a] = *(const u32x4*)(abase + a * 32 * PITCH + foff[0]);

@@ -35,7 +35,7 @@ class DDIMSampler(object):
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.use_graph = use_graph
-        self._static = None
+        self._static = None       # captured step + its static buffers (state, step counter, copies of the conditioning)
         self._graph_key = None
 
     # ---- schedule (ddim.py:24-57, utils_diffusion.py:79-91) -----------------------------------------------------
@@ -73,54 +73,118 @@ class DDIMSampler(object):
             self._static, self._graph_key = None, None
 
     # ---- public API (ddim.py:60-132) ------------------------------------------------------------------------------
+    @staticmethod
+    def _cond_signature(c):
+        """Structure + shapes + dtypes of a conditioning dict (NOT its pointers: the captured step reads sampler-owned
+        static copies, so a new window's tensors of the same shape reuse the graph)."""
+        if not isinstance(c, dict):
+            return None if c is None else ("tensor", tuple(c.shape), c.dtype)
+        return tuple((k, tuple((tuple(t.shape), t.dtype) for t in (v if isinstance(v, (list, tuple)) else [v])))
+                     for k, v in sorted(c.items()))
+
+    @staticmethod
+    def _clone_cond(c):
+        if not isinstance(c, dict):
+            return None if c is None else c.detach().clone()
+        return {k: [t.detach().clone() for t in v] if isinstance(v, (list, tuple)) else v.detach().clone() for k, v in c.items()}
+
+    @staticmethod
+    def _copy_cond(dst, src):
+        if dst is None:
+            return
+        if not isinstance(dst, dict):
+            dst.copy_(src)
+            return
+        for k, v in dst.items():
+            if isinstance(v, list):
+                for d, t in zip(v, src[k]):
+                    d.copy_(t)
+            else:
+                v.copy_(src[k])
+
+    def _prepare(self, conds, T):
+        """Project / refresh the cross-attention K/V of every conditioning OUTSIDE the captured step and return the model's
+        validity token (weights generation + K/V buffer identity). Models without the hook (stubs) return None."""
+        prep = getattr(self.model, "prepare_conditioning", None)
+        if prep is None:
+            return None
+        return tuple(prep(c, T) for c in conds if c is not None)
+
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
                quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
                corrector_kwargs=None, verbose=True, schedule_verbose=False, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1., unconditional_conditioning=None, precision=None, fs=None,
                timestep_spacing='uniform', guidance_rescale=0.0, **kwargs):
+        """Same signature and return value as the reference. Two extra, optional keywords (popped, never forwarded to the
+        model): ``noise_generator`` — a device ``torch.Generator`` for x_T (when not given) and the eta > 0 step noise, so a
+        window's result does not depend on what ran before it; ``strict_rng`` — draw one ``randn`` per step even at eta == 0
+        like ``noise_like`` in ddim.py:271 does (keeps the global RNG stream aligned with the reference across calls; forces
+        the eager path). ``precision`` is accepted and ignored (the compute mode is a property of the model here)."""
         if mask is not None or x0 is not None or score_corrector is not None or quantize_x0 or noise_dropout > 0.:
             raise NotImplementedError("mask / x0 / score_corrector / quantize_x0 / noise_dropout are not used by Geo4D "
                                       "inference (test_geo4d.py:212-227) and have no HIP path")
         if self.model.parameterization != "v":
             raise NotImplementedError("only the v-parameterisation of configs/inference_geo4d.yaml:43 is built")
+        gen = kwargs.pop("noise_generator", None)
+        strict_rng = bool(kwargs.pop("strict_rng", False))
         self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
         size = (batch_size,) + tuple(shape)
         dev = self.model.device
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         total = len(self.ddim_timesteps)
         kwargs.pop("clean_cond", None)
-        graph_ok = self.use_graph and eta == 0. and callback is None and img_callback is None and total > 2
+        graph_ok = (self.use_graph and eta == 0. and not strict_rng and callback is None and img_callback is None and total > 2)
         # 3-way guidance of ddim_multiplecond.py:229-234 (image yes / text "" as a third evaluation)
         uc_img = kwargs.get("unconditional_conditioning_img_nonetext") if (self.multicond and cfg) else None
         if self.multicond and cfg and uc_img is None:
             raise ValueError("DDIMSampler (multiple cond): unconditional_conditioning_img_nonetext is required when CFG is on")
         cfg_img = kwargs.get("cfg_img")
         cfg_img = unconditional_guidance_scale if cfg_img is None else cfg_img
-        # static buffers: a captured step graph is reused across sample() calls with the same shapes / conditioning
-        ptrs = lambda c: tuple((t.data_ptr(), t._version) for v in (c or {}).values() for t in (v if isinstance(v, (list, tuple)) else [v])) if isinstance(c, dict) else ()   # _version: an in-place edit of a conditioning tensor invalidates the captured step (its context K/V are baked in)
-        cond_ptrs = ptrs(conditioning) + ((ptrs(unconditional_conditioning), ptrs(uc_img), float(unconditional_guidance_scale),
-                                          float(cfg_img), float(guidance_rescale)) if cfg else ())
-        key = (size, S, timestep_spacing, cond_ptrs, None if fs is None else fs.data_ptr(), tuple(sorted(kwargs)))
-        cached = self._static if (graph_ok and self._graph_key == key) else None
-        if cached is not None:
-            g, img, ts, idx, pred_x0 = cached
-        else:
-            g = None
-            img = torch.empty(size, device=dev, dtype=torch.float32)
-            ts = torch.empty((batch_size,), dtype=torch.int64, device=dev)
-            idx = torch.empty((1,), dtype=torch.int32, device=dev)
-            pred_x0 = torch.empty_like(img)
-        img.copy_(torch.randn(size, device=dev) if x_T is None else x_T.to(dev).float())
+        T_frames = size[2] if len(size) == 5 else 1
+        # The captured step reads SAMPLER-OWNED static copies of x / t / fs / every conditioning tensor; a later call with the
+        # same shapes (the next window of a clip) copies its values in, refreshes the context K/V in place and replays.
+        sig = self._cond_signature
+        key = (size, S, timestep_spacing, sig(conditioning),
+               (sig(unconditional_conditioning), sig(uc_img), float(unconditional_guidance_scale), float(cfg_img),
+                float(guidance_rescale)) if cfg else (),
+               None if fs is None else (tuple(fs.shape), fs.dtype), tuple(sorted(kwargs)))
+        st = self._static if (graph_ok and self._graph_key == key) else None
+        if st is not None:
+            self._copy_cond(st["cond"], conditioning)
+            if cfg:
+                self._copy_cond(st["uc"], unconditional_conditioning)
+                self._copy_cond(st["uc_img"], uc_img)
+            if fs is not None:
+                st["fs"].copy_(fs)
+            if self._prepare([st["cond"], st["uc"], st["uc_img"]], T_frames) != st["token"]:
+                st = None                      # weights re-packed / K/V buffers replaced since the capture: capture again
+        if st is None:
+            own = graph_ok                       # eager runs use the caller's tensors directly
+            st = {"g": None,
+                  "img": torch.empty(size, device=dev, dtype=torch.float32),
+                  "ts": torch.empty((batch_size,), dtype=torch.int64, device=dev),
+                  "idx": torch.empty((1,), dtype=torch.int32, device=dev),
+                  "cond": self._clone_cond(conditioning) if own else conditioning,
+                  "uc": (self._clone_cond(unconditional_conditioning) if own else unconditional_conditioning) if cfg else None,
+                  "uc_img": (self._clone_cond(uc_img) if own else uc_img) if cfg else None,
+                  "fs": None if fs is None else (fs.detach().clone() if own else fs)}
+            st["pred_x0"] = torch.empty_like(st["img"])
+        img, ts, idx, pred_x0 = st["img"], st["ts"], st["idx"], st["pred_x0"]
+        c_cond, c_uc, c_img, c_fs = st["cond"], st["uc"], st["uc_img"], st["fs"]
+        mkw = dict(kwargs)
+        if "unconditional_conditioning_img_nonetext" in mkw and c_img is not None:
+            mkw["unconditional_conditioning_img_nonetext"] = c_img   # forwarded (and ignored) like ddim.py:217 does
+        img.copy_(torch.randn(size, device=dev, generator=gen) if x_T is None else x_T.to(dev).float())
         idx.fill_(total - 1)
         intermediates = {'x_inter': [img.clone()], 'pred_x0': [img.clone()]}
 
         def model_out():
             if not cfg:
-                return self.model.apply_model(img, ts, conditioning, fs=fs, **kwargs)
-            e_c = self.model.apply_model(img, ts, conditioning, fs=fs, **kwargs)
-            e_u = self.model.apply_model(img, ts, unconditional_conditioning, fs=fs, **kwargs)
-            e_i = self.model.apply_model(img, ts, uc_img, fs=fs, **kwargs) if uc_img is not None else None
+                return self.model.apply_model(img, ts, c_cond, fs=c_fs, **mkw)
+            e_c = self.model.apply_model(img, ts, c_cond, fs=c_fs, **mkw)
+            e_u = self.model.apply_model(img, ts, c_uc, fs=c_fs, **mkw)
+            e_i = self.model.apply_model(img, ts, c_img, fs=c_fs, **mkw) if c_img is not None else None
             # ddim.py:216-229 / ddim_multiplecond.py:229-236 + rescale_noise_cfg (utils_diffusion.py:147-158): one fused HIP op
             f = lambda t: None if t is None else t.float().contiguous()
             return ops.cfg_combine(f(e_c), f(e_u), f(e_i), scale=unconditional_guidance_scale, cfg_img=cfg_img,
@@ -132,11 +196,19 @@ class DDIMSampler(object):
             ops.ddim_step(img, v.float().contiguous(), self.coef, idx, noise=noise, pred_x0=pred_x0)
             ops.advance_index(idx, -1)
 
-        if graph_ok and g is not None:
-            for _ in range(total):
-                g.replay()
+        def log(i):          # ddim.py:195-197: index = total - i - 1
+            index = total - i - 1
+            if index % log_every_t == 0 or index == total - 1:
+                intermediates['x_inter'].append(img.clone())
+                intermediates['pred_x0'].append(pred_x0.clone())
+
+        if graph_ok and st["g"] is not None:
+            for i in range(total):
+                st["g"].replay()
+                log(i)
         elif graph_ok:
             step()                                   # eager first step: packs weights, fills the context K/V cache
+            log(0)
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -144,22 +216,24 @@ class DDIMSampler(object):
                 with torch.cuda.graph(g, stream=side):
                     step()                           # recorded, not executed
             torch.cuda.current_stream().wait_stream(side)
-            for _ in range(total - 1):
+            for i in range(1, total):
                 g.replay()
-            self._static, self._graph_key = (g, img, ts, idx, pred_x0), key
-            self._keepalive = (conditioning, unconditional_conditioning, uc_img, fs)   # keeps the captured device pointers valid and unique
+                log(i)
+            st["g"] = g
+            st["token"] = self._prepare([c_cond, c_uc, c_img], T_frames)   # K/V already cached: returns the identity the graph baked in
+            self._static, self._graph_key = st, key
         else:
             for i in range(total):
                 noise = None
                 if eta > 0.:
-                    noise = torch.randn(size, device=dev) * temperature
+                    noise = torch.randn(size, device=dev, generator=gen) * temperature
+                elif strict_rng:
+                    torch.randn(size, device=dev, generator=gen)          # drawn and multiplied by sigma = 0 in the reference
                 step(noise)
                 if callback:
                     callback(i)
                 if img_callback:
                     img_callback(pred_x0, i)
-        if graph_ok:
-            img, pred_x0 = img.clone(), pred_x0.clone()   # the static buffers are overwritten by the next call
-        intermediates['x_inter'].append(img)
-        intermediates['pred_x0'].append(pred_x0)
-        return img, intermediates
+                log(i)
+        # the static buffers are overwritten by the next call: hand out copies
+        return (img.clone() if graph_ok else img), intermediates

@@ -30,6 +30,12 @@ class DiffusionWrapper(nn.Module):
         # the channel concat of ddpm3d.py:2542 happens inside the token-layout kernel (two sources)
         return self.diffusion_model(x, t, context=cc, c_concat=extra, **kwargs)
 
+    def prepare(self, c_crossattn, T):
+        """Project (or refresh in place) the cross-attention K/V of this conditioning outside a captured step; returns the
+        U-Net's validity token (see UNetModel.prepare_context)."""
+        cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+        return self.diffusion_model.prepare_context(cc, T)
+
 
 def _beta_schedule(n, linear_start, linear_end, zero_snr):
     betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n, dtype=torch.float64, device="cpu") ** 2).numpy()
@@ -96,6 +102,12 @@ class LatentDiffusion(nn.Module):
             cond = {"c_crossattn": cond if isinstance(cond, list) else [cond]}
         out = self.model(x_noisy, t, **cond, **kwargs)
         return out[0] if isinstance(out, tuple) else out
+
+    def prepare_conditioning(self, cond, T):
+        """Hook used by the samplers before replaying a captured step (geo4d_amd/ddim.py)."""
+        if not isinstance(cond, dict):
+            cond = {"c_crossattn": cond if isinstance(cond, list) else [cond]}
+        return self.model.prepare(cond["c_crossattn"], T)
 
     # ---- first stage (ddpm3d.py:802-870, 935-936) -----------------------------------------------------------------
     def _decode(self, fn, z):

@@ -10,7 +10,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, F16, F32, Attention, ConvGemm, GroupNorm
+from ._lib import BF16, BF16X3, F16, F32, Attention, ConvGemm, GroupNorm
+from .precision import resolve as _resolve_precision
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _TD = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -24,8 +25,18 @@ def dt_code(dtype):
 
 
 def k_align(dtype):
-    """K / Cin granularity of conv_gemm in elements: one 128-byte LDS slab."""
-    return 32 if dtype == torch.float32 else 64
+    """K / Cin granularity of conv_gemm in elements: one 128-byte LDS slab (4-byte elements for f32 and bf16x3)."""
+    return 32 if _resolve_precision(dtype).storage == torch.float32 else 64
+
+
+def is_split(w, other):
+    """True when `w` is a PRE-SPLIT bf16x3 operand (pack.split_bf16: bf16 [rows, 2K]) multiplied with an f32 operand."""
+    return w.dtype == torch.bfloat16 and other.dtype == torch.float32
+
+
+def kdim(w, other):
+    """Logical K extent of a 2-D operand (a pre-split operand stores 2 bf16 per K element)."""
+    return w.shape[1] // 2 if is_split(w, other) else w.shape[1]
 
 
 def _stream():
@@ -114,10 +125,26 @@ def workspace(device):
 def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout=1, Wout=1, KT=1, KH=1, KW=1,
               pt=0, ph=0, pw=0, stride=1, ups=1, bias=None, bias_per_row=False, rowbias=None, rowbias_div=0,
               residual=None, ldr=0, act=0, out_nchw=False, alpha=1.0, batch=1, a_bs=0, w_bs=0, o_bs=0, r_bs=0,
-              tile_hint=0, split_k=0):
+              tile_hint=0, split_k=0, x3=False):
+    """`lda` / `ldw` / `a_bs` / `w_bs` are strides of the tensors as passed (torch elements). bf16x3 mode is selected by the
+    operands: f32 activations against a pre-split bf16 weight (either side), or two f32 operands with `x3=True`."""
     lib = _lib.load()
     _dev(a, "A"); _dev(w, "W"); _dev(out, "out")
-    assert a.dtype == w.dtype, (a.dtype, w.dtype)
+    a_split, w_split = is_split(a, w), is_split(w, a)
+    if a_split or w_split:
+        code = BF16X3
+        if a_split:
+            assert lda % 2 == 0 and a_bs % 2 == 0
+            lda, a_bs = lda // 2, a_bs // 2          # -> K elements (4 bytes each)
+        else:
+            assert ldw % 2 == 0 and w_bs % 2 == 0
+            ldw, w_bs = ldw // 2, w_bs // 2
+    else:
+        assert a.dtype == w.dtype, (a.dtype, w.dtype)
+        code = dt_code(a.dtype)
+        if x3:
+            assert a.dtype == torch.float32, "x3=True multiplies two f32 operands with the bf16x3 scheme"
+            code = BF16X3
     p = ConvGemm()
     p.A, p.W, p.O = a.data_ptr(), w.data_ptr(), out.data_ptr()
     p.bias, p.rowbias, p.R = _ptr(bias), _ptr(rowbias), _ptr(residual)
@@ -134,9 +161,10 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.T, p.Hin, p.Win, p.Hout, p.Wout = T, Hin, Win, Hout, Wout
     p.KT, p.KH, p.KW, p.pt, p.ph, p.pw, p.stride, p.ups = KT, KH, KW, pt, ph, pw, stride, ups
     p.rowbias_div, p.bias_per_row, p.act = rowbias_div, int(bias_per_row), act
-    p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = dt_code(a.dtype), dt_code(out.dtype), int(out_nchw), tile_hint
+    p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = code, dt_code(out.dtype), int(out_nchw), tile_hint
     p.alpha, p.split_k = alpha, split_k
     p.debug_ablate = 0
+    p.a_split, p.w_split = int(a_split), int(w_split)
     ws, zeros = workspace(a.device)
     p.workspace, p.workspace_bytes, p.zeros = ws.data_ptr(), ws.numel(), zeros.data_ptr()
 
@@ -146,6 +174,8 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
 
     if tile_hint == 0 and split_k == 0:
         key = f"{p.dtype}/{p.out_dtype}|{M}x{N}x{K}|c{Cin}|t{KT}{KH}{KW}s{stride}u{ups}|a{act}r{int(residual is not None)}n{int(out_nchw)}|b{batch}"
+        if code == BF16X3:
+            key += f"|x{int(a_split)}{int(w_split)}"
         cfg = _tune_table().get(key)
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
@@ -165,7 +195,7 @@ def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, a
     """x [M, K] (row pitch free), w packed [N, K]; GEGLU (act=2) returns [M, N/2]."""
     M, K = x.shape
     N = w.shape[0]
-    assert w.shape[1] == K, (w.shape, x.shape)
+    assert kdim(w, x) == K, (w.shape, x.shape)
     if out is None:
         out = torch.empty((M, N // 2 if act == 2 else N), device=x.device, dtype=out_dtype or x.dtype)
     return conv_gemm(x, w, out, M=M, N=N, K=K, Cin=K, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), bias=bias,
@@ -186,7 +216,7 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1
     Wout = (Ws + 2 * pad + pad_end - KW) // stride + 1
     M = F * Hout * Wout
     assert x.shape[0] == F * Hin * Win, (x.shape, F, Hin, Win)
-    assert w.shape[1] == KH * KW * Cin, (w.shape, KH, KW, Cin)
+    assert kdim(w, x) == KH * KW * Cin, (w.shape, KH, KW, Cin)
     if out is None:
         if out_nchw:
             out = torch.empty((F // T, N, T, Hout, Wout), device=x.device, dtype=out_dtype or torch.float32)
@@ -205,7 +235,7 @@ def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None):
     Cin = x.shape[1]
     N = w.shape[0]
     M = B * T * HW
-    assert x.shape[0] == M and w.shape[1] == 3 * Cin
+    assert x.shape[0] == M and kdim(w, x) == 3 * Cin
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=x.dtype)
     return conv_gemm(x, w, out, M=M, N=N, K=3 * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), T=T, Hin=HW, Win=1,
@@ -213,10 +243,11 @@ def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None):
                      ldr=_ld(residual) if residual is not None else 0)
 
 
-def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias_per_row=False, alpha=1.0):
-    """out[z] = alpha * a[z] @ b[z]^T (+bias); a [.., K] rows, b [.., K] rows (both K-major)."""
+def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias_per_row=False, alpha=1.0, x3=False):
+    """out[z] = alpha * a[z] @ b[z]^T (+bias); a [.., K] rows, b [.., K] rows (both K-major). `x3`: both operands are f32
+    activations to be multiplied with the bf16x3 scheme (the VAE AttnBlock GEMMs of the bf16x3 mode)."""
     return conv_gemm(a, b, out, M=M, N=N, K=K, Cin=K, lda=_ld(a), ldw=_ld(b), ldo=_ld(out), batch=batch, a_bs=a_bs,
-                     w_bs=b_bs, o_bs=o_bs, bias=bias, bias_per_row=bias_per_row, alpha=alpha)
+                     w_bs=b_bs, o_bs=o_bs, bias=bias, bias_per_row=bias_per_row, alpha=alpha, x3=x3)
 
 
 _gn_ws = {}
@@ -264,7 +295,7 @@ def softmax_rows(x, scale, out_dtype):
     return out
 
 
-def attention(q, kv, *, B, H, Nq, scale, out=None):
+def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False):
     """q [B*Nq, >=H*64] view; kv = list of (k, vt, Nk, kv_div, vt_bs): k [(B/kv_div)*Nk, >=H*64] view, vt = V TRANSPOSED
     as a [>=H*64, ld] view (row = channel, column = key) whose batch b' starts vt_bs elements after batch b'-1."""
     lib = _lib.load()
@@ -278,7 +309,11 @@ def attention(q, kv, *, B, H, Nq, scale, out=None):
         assert k.dtype == q.dtype and vt.dtype == q.dtype
         p.k[i], p.vt[i], p.ldk[i], p.ldvt[i], p.vt_bs[i], p.Nk[i], p.kv_div[i] = k.data_ptr(), vt.data_ptr(), _ld(k), _ld(vt), vt_bs, nk, div
     p.zeros = workspace(q.device)[1].data_ptr()
-    p.B, p.H, p.Nq, p.nseg, p.head_dim, p.dtype, p.scale = B, H, Nq, len(kv), 64, dt_code(q.dtype), scale
+    code = dt_code(q.dtype)
+    if x3:
+        assert q.dtype == torch.float32, "x3 attention runs on f32 q / k / v^T"
+        code = BF16X3
+    p.B, p.H, p.Nq, p.nseg, p.head_dim, p.dtype, p.scale = B, H, Nq, len(kv), 64, code, scale
     _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
     return out
 
@@ -286,7 +321,7 @@ def attention(q, kv, *, B, H, Nq, scale, out=None):
 def linear_t_batched(w, x, batch, rows, dtype_align=None):
     """Per-batch operand-swapped projection: x [batch*rows, K] -> out [batch, N, rows_pad] with out[b, n, m] =
     sum_k w[n, k] x[b*rows + m, k]; rows_pad = rows rounded up to a 16-byte multiple (zero filled). This is V^T per frame."""
-    N, K = w.shape
+    N, K = w.shape[0], kdim(w, x)
     epc = 4 if x.dtype == torch.float32 else 8
     rp = (rows + epc - 1) // epc * epc
     out = (torch.zeros if rp != rows else torch.empty)((batch, N, rp), device=x.device, dtype=x.dtype)
@@ -297,7 +332,7 @@ def linear_t_batched(w, x, batch, rows, dtype_align=None):
 def linear_t(w, x, bias=None, *, out=None, pad_cols=None):
     """Operand-swapped projection: out[n, m] = sum_k w[n, k] * x[m, k] (+ bias[n]) -> [N, M]: the transposed layout the
     attention kernel wants for V. `pad_cols`: allocate zero-filled columns up to this count (16-byte row alignment)."""
-    N, K = w.shape
+    N, K = w.shape[0], kdim(w, x)
     M = x.shape[0]
     if out is None:
         cols = pad_cols or M

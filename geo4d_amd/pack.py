@@ -6,6 +6,24 @@ GEGLU projections get their value/gate rows interleaved in blocks of 32 so the G
 import torch
 
 from .ops import k_align
+from .precision import resolve
+
+
+def split_bf16(w):
+    """[N, K] fp32 (K % 8 == 0) -> the pre-split operand format of the bf16x3 GEMM: a bf16 tensor [N, 2K] holding, per 8
+    K-elements, [8 x hi | 8 x lo] with hi = bf16(w), lo = bf16(w - hi) — 32 bytes, the footprint of the 8 f32 it replaces."""
+    n, k = w.shape
+    assert k % 8 == 0
+    w = w.float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi.reshape(n, k // 8, 8), lo.reshape(n, k // 8, 8)], dim=2).reshape(n, 2 * k).contiguous()
+
+
+def cast(w, dtype):
+    """2-D K-major weight -> operand format of the compute mode (``dtype``: Precision, name or torch dtype)."""
+    prec = resolve(dtype)
+    return split_bf16(w) if prec.x3 else w.to(prec.storage).contiguous()
 
 
 def pad_to(n, m):
@@ -18,7 +36,7 @@ def pack_linear(w, dtype):
     kp = pad_to(w.shape[1], k_align(dtype))
     if kp != w.shape[1]:
         w = torch.nn.functional.pad(w, (0, kp - w.shape[1]))
-    return w.to(dtype).contiguous()
+    return cast(w, dtype)
 
 
 def pack_conv2d(w, dtype, cin_pad=None):
@@ -28,14 +46,14 @@ def pack_conv2d(w, dtype, cin_pad=None):
     w = w.permute(0, 2, 3, 1)
     if cp != ci:
         w = torch.nn.functional.pad(w, (0, cp - ci))
-    return w.reshape(co, kh * kw * cp).to(dtype).contiguous()
+    return cast(w.reshape(co, kh * kw * cp), dtype)
 
 
 def pack_conv3d_t(w, dtype):
     """nn.Conv3d weight [Cout, Cin, 3, 1, 1] -> [Cout, 3*Cin]."""
     co, ci, kt, kh, kw = w.shape
     assert kh == 1 and kw == 1
-    return w.reshape(co, ci, kt).permute(0, 2, 1).reshape(co, kt * ci).to(dtype).contiguous()
+    return cast(w.reshape(co, ci, kt).permute(0, 2, 1).reshape(co, kt * ci), dtype)
 
 
 def geglu_perm(inner, device=None):

@@ -89,17 +89,29 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
         model.get_learned_conditioning(prompts)       # raises: the OpenCLIP / Resampler front-end is N3
     if "c_concat" not in cond and model.model.conditioning_key == "hybrid":
         cond = dict(cond, c_concat=[get_latent_z(model, videos)])       # test_geo4d.py:159-170 (modality != img_vidpc)
+    def with_latent(c):
+        # test_geo4d.py:184-195: the unconditional dicts carry the SAME video latent (uc['c_concat'] = [img_cat_cond])
+        if isinstance(c, dict) and "c_concat" not in c and "c_concat" in cond:
+            c = dict(c, c_concat=cond["c_concat"])
+        return c
     uc = None
     if unconditional_guidance_scale != 1.0:
         uc = kwargs.pop("unconditional_conditioning", None)
         if uc is None:
             raise NotImplementedError("CFG needs precomputed unconditional conditioning (front-end is N3)")
+        uc = with_latent(uc)
     if multiple_cond_cfg and cfg_img != 1.0 and uc is not None:
         if kwargs.get("unconditional_conditioning_img_nonetext") is None:
             raise NotImplementedError("multiple_cond_cfg needs precomputed unconditional_conditioning_img_nonetext (front-end is N3)")
+        kwargs["unconditional_conditioning_img_nonetext"] = with_latent(kwargs["unconditional_conditioning_img_nonetext"])
     else:
         kwargs.update({"unconditional_conditioning_img_nonetext": None})
-    sampler = (DDIMSamplerMulticond if multiple_cond_cfg else DDIMSampler)(model)
+    # one sampler per (model, class): its captured step graph and static conditioning buffers are reused by every later window
+    cls = DDIMSamplerMulticond if multiple_cond_cfg else DDIMSampler
+    cache = model.__dict__.setdefault("_geo4d_samplers", {})
+    sampler = cache.get(cls)
+    if sampler is None:
+        sampler = cache[cls] = cls(model)
     variants = []
     for _ in range(n_samples):
         samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:], verbose=False,
@@ -123,9 +135,10 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
     ``w`` runs on rank ``w % world`` and ONE all-gather returns every window's decoded maps on every rank:
     ``(slices, maps [n_windows, 11, video_length, H, W])``; with ``with_cameras`` also the per-window camera-to-world
     matrices ``traj [n_windows, video_length, 4, 4]`` from the ray / ray-moment maps (test_geo4d.py:455-458, computed on the
-    device by ``geo4d_amd.rays``, no host sync in the loop). Noise and posterior sampling are seeded PER WINDOW
-    (``seed``, window index), so the result does not depend on the number of GPUs — unlike the reference's single
-    sequential RNG stream, which cannot be reproduced across a sharded loop."""
+    device by ``geo4d_amd.rays``, no host sync in the loop). The initial noise, the posterior sampling of the VAE encode and
+    (eta > 0) the per-step noise are all seeded PER WINDOW (``seed``, window index), so the result does not depend on the
+    number of GPUs or on which windows a rank ran before — unlike the reference's single sequential RNG stream, which
+    cannot be reproduced across a sharded loop."""
     from . import dist as gdist
     synthesize = synthesize or image_guided_synthesis
     B, C, T, H, W = videos_all.shape
@@ -141,6 +154,8 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
         videos = videos_all[:, :, slices[wi]].clone()
         wseed = (int(seed) * 1000003 + wi) % (2 ** 63 - 1)
         x_T = torch.randn(noise_shape, generator=torch.Generator().manual_seed(wseed)).to(videos_all.device)
+        if ddim_eta > 0.0 and videos_all.is_cuda:   # per-window device stream for the stochastic step noise (eta > 0)
+            kwargs["noise_generator"] = torch.Generator(device=videos_all.device).manual_seed(wseed)
         ctx = context(videos) if callable(context) else context
         with torch.random.fork_rng(devices=[]):
             torch.manual_seed(wseed)                                   # posterior sampling noise of the VAE encode

@@ -1,0 +1,69 @@
+"""Compute-precision modes of the HIP engine.
+
+=========  ===================  ============================  ==========================================================
+name       activation storage   GEMM / attention arithmetic   point-map parity vs the fp32 reference (1e-3 is the bar)
+=========  ===================  ============================  ==========================================================
+``bf16``   bfloat16             bf16 MFMA, fp32 accumulate    ~2e-2  (8-bit mantissas through ~300 GEMMs)
+``f16``    float16              f16 MFMA, fp32 accumulate     ~2.5e-3
+``bf16x3`` float32              3 bf16 MFMAs per product on   < 1e-4: meets the bar at ~1/3 of the bf16 MFMA rate
+                                a hi/lo split of each operand
+``f32``    float32              v_mfma_f32_32x32x2_f32        ~2e-6 (exact f32; 1/16 of the bf16 MFMA rate)
+=========  ===================  ============================  ==========================================================
+
+Why ``bf16x3`` exists: rounding ONLY the weights of the U-Net to f16 (activations exact) already costs 1.4e-3 on the point
+map, rounding only the GEMM inputs another 1.2e-3 (tests/precision_sim.py, tests/test_precision_floor.py) — no single pass
+over 11-bit (f16) or 8-bit (bf16) mantissas can meet 1e-3 on this network, whatever is done to the residual streams. The
+split ``x = hi + lo`` (two bf16) carries ~16 mantissa bits; ``x.w ~ hi.hi + hi.lo + lo.hi`` needs three MFMAs and an fp32
+accumulator, which is what the matrix cores provide. Activations stay f32 in memory (every HBM-bound kernel simply runs its
+f32 instantiation), weights are split once at pack time.
+"""
+import os
+
+import torch
+
+
+class Precision:
+    __slots__ = ("name", "storage", "x3")
+
+    def __init__(self, name, storage, x3=False):
+        self.name, self.storage, self.x3 = name, storage, x3
+
+    def __repr__(self):
+        return f"Precision({self.name})"
+
+    def __eq__(self, other):
+        other = _coerce(other)
+        return isinstance(other, Precision) and other.name == self.name
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+BF16 = Precision("bf16", torch.bfloat16)
+F16 = Precision("f16", torch.float16)
+F32 = Precision("f32", torch.float32)
+BF16X3 = Precision("bf16x3", torch.float32, x3=True)
+
+_BY_NAME = {"bf16": BF16, "bfloat16": BF16, "f16": F16, "fp16": F16, "float16": F16, "f32": F32, "fp32": F32, "float32": F32,
+            "bf16x3": BF16X3, "bf16_3x": BF16X3, "3xbf16": BF16X3}
+_BY_TORCH = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}
+
+
+def _coerce(d):
+    if isinstance(d, Precision):
+        return d
+    if isinstance(d, torch.dtype):
+        return _BY_TORCH.get(d)
+    if isinstance(d, str):
+        return _BY_NAME.get(d.lower())
+    return None
+
+
+def resolve(d=None):
+    """None -> $GEO4D_DTYPE or bf16; str / torch.dtype / Precision -> Precision."""
+    if d is None:
+        d = os.environ.get("GEO4D_DTYPE", "bf16")
+    p = _coerce(d)
+    if p is None:
+        raise ValueError(f"geo4d_amd: unknown compute dtype {d!r} (bf16, f16, bf16x3, f32)")
+    return p

@@ -6,8 +6,8 @@ shipped config, including the reference's ``temopral_conv`` spelling, openaimode
 same output ``[B,16,T,h,w]`` — but nothing is computed by PyTorch: ``forward`` enqueues hand-written HIP kernels
 (include/geo4d_hip.h) on the current stream, is free of host synchronisation and therefore hipGraph-capturable.
 
-Engine layout: activations are channels-last tokens ``[(b t) h w, C]`` in the compute dtype (bf16 by default, f16, or
-f32 = exact-parity mode); the frame-major token order is kept through the temporal layers (the temporal kernels
+Engine layout: activations are channels-last tokens ``[(b t) h w, C]`` in the storage dtype of the compute mode (bf16 by
+default, f16; f32 for ``bf16x3`` = the mode that meets the 1e-3 parity bar, and for ``f32`` = exact parity, see precision.py); the frame-major token order is kept through the temporal layers (the temporal kernels
 gather across T themselves), so no rearrange is ever materialised. Fusions vs. the reference op list: bias / timestep
 embedding / residual adds / GEGLU / SiLU live in GEMM epilogues, q-k-v projections are one GEMM, nearest-2x upsample
 is folded into the conv gather, cross-attention K/V of the (step-constant) context are projected once and cached, all
@@ -20,15 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, pack
-
-_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16,
-           "float16": torch.float16, "f32": torch.float32, "fp32": torch.float32, "float32": torch.float32}
-
-
-def resolve_dtype(d):
-    if isinstance(d, torch.dtype):
-        return d
-    return _DTYPES[str(d or os.environ.get("GEO4D_DTYPE", "bf16")).lower()]
+from .precision import resolve as resolve_dtype   # compute mode: "bf16" | "f16" | "bf16x3" | "f32" (geo4d_amd/precision.py)
 
 
 class ParamTree(nn.Module):
@@ -210,6 +202,7 @@ class UNetModel(ParamTree):
         init_params_(self)
         self._packed = None
         self._ctx_cache = {}
+        self.generation = 0
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     def all_layers(self):
@@ -229,11 +222,17 @@ class UNetModel(ParamTree):
     def invalidate(self):
         self._packed = None
         self._ctx_cache = {}
+        self.generation = getattr(self, "generation", 0) + 1   # packed weights / K/V tensors of older captures are gone
 
     def set_compute_dtype(self, d):
         self.compute_dtype = resolve_dtype(d)
         self.invalidate()
         return self
+
+    @property
+    def storage_dtype(self):
+        """torch dtype of the activations (and of the cached context K/V) in the current compute mode."""
+        return self.compute_dtype.storage
 
     def _apply(self, fn, *a, **k):  # .cuda() / .to(): repack on the new device
         self.invalidate()
@@ -278,7 +277,7 @@ class UNetModel(ParamTree):
             p, e = L.prefix, {}
             if L.kind == "conv_in":
                 e["w"] = pack.pack_conv2d(sd[p + ".weight"], dt); e["b"] = f32(p + ".bias")
-                e["cpad"] = e["w"].shape[1] // 9
+                e["cpad"] = pack.pad_to(L.cin, ops.k_align(dt))
             elif L.kind == "res":
                 e["gn1"], e["gn2"] = norm(p + ".in_layers.0"), norm(p + ".out_layers.0")
                 e["w1"], e["b1"] = pack.pack_conv2d(sd[p + ".in_layers.2.weight"], dt), f32(p + ".in_layers.2.bias")
@@ -325,35 +324,59 @@ class UNetModel(ParamTree):
 
     # ---- cross-attention K/V of the context: constant over DDIM steps -> projected once --------------------
     def _context_kv(self, P, context, B, T):
-        key = (context.data_ptr(), context._version, tuple(context.shape), self.compute_dtype)
+        """K / V^T of the cross-attention context for every spatial transformer, cached per context BUFFER.
+
+        The cache key is the buffer identity (pointer, shape, compute dtype); the tensor's ``_version`` is stored in the
+        entry. A hit whose version moved (the caller refilled the same buffer, e.g. the sampler's static conditioning
+        between windows) re-projects IN PLACE into the same K/V tensors, so device pointers baked into a captured
+        hipGraph stay valid and see the new values. Evicting an entry or re-packing the weights bumps ``generation``;
+        samplers put it in their graph key and re-capture when it moves (a captured step must never outlive its K/V)."""
+        key = (context.data_ptr(), tuple(context.shape), context.dtype, self.compute_dtype)
         hit = self._ctx_cache.get(key)
-        if hit is not None:
-            return hit
+        if hit is not None and hit["version"] == context._version:
+            return hit["kv"]
         L = context.shape[1]
         if L != 77 + 16 * T:
             raise NotImplementedError(f"context length {L} != 77 + 16*T ({77 + 16 * T}): only the per-frame image-token "
                                       "layout of Geo4D inference (openaimodel3d.py:576-580) has a HIP path")
-        dt = self.compute_dtype
+        dt = self.storage_dtype
         ctx = context.to(dt)
         text = ctx[:, :77].reshape(B * 77, -1).contiguous()
         img = ctx[:, 77:].reshape(B * T * 16, -1).contiguous()
-        k_t = ops.linear(text, P["k_text"])                                   # every layer's text keys: [B*77, sum C]
-        k_i = ops.linear(img, P["k_img"]) if P["k_img"] is not None else None
-        vt_t, vt_i = {}, {}
+        if hit is None:
+            k_t = k_i = None
+            vt_t, vt_i = {}, {}
+        else:
+            k_t, k_i, vt_t, vt_i, _ = hit["kv"]
+        k_t = ops.linear(text, P["k_text"], out=k_t)                          # every layer's text keys: [B*77, sum C]
+        k_i = ops.linear(img, P["k_img"], out=k_i) if P["k_img"] is not None else None
         for L in self.all_layers():                                            # values, transposed per layer (V^T rows = channels)
             if L.kind != "spatial":
                 continue
             e = P[L.prefix]
-            v = torch.zeros((B, L.inner, 80), device=ctx.device, dtype=dt)     # 77 keys padded to a 16-byte multiple
+            v = vt_t.get(L.prefix)
+            if v is None:                                                      # 77 keys padded to a 16-byte multiple (pad stays 0)
+                v = vt_t[L.prefix] = torch.zeros((B, L.inner, 80), device=ctx.device, dtype=dt)
             for b in range(B):
                 ops.linear_t(e["wv_text"], text[b * 77:(b + 1) * 77], out=v[b])
-            vt_t[L.prefix] = v
             if k_i is not None:
-                vt_i[L.prefix] = ops.linear_t(e["wv_img"], img)                # [C, B*T*16], frame f at columns 16f..
-        if len(self._ctx_cache) >= 4:
-            self._ctx_cache.pop(next(iter(self._ctx_cache)))
-        self._ctx_cache[key] = (k_t, k_i, vt_t, vt_i, context)  # keep `context` alive so data_ptr stays unique
-        return self._ctx_cache[key]
+                vt_i[L.prefix] = ops.linear_t(e["wv_img"], img, out=vt_i.get(L.prefix))   # [C, B*T*16], frame f at columns 16f..
+        kv = (k_t, k_i, vt_t, vt_i, context)   # keeps `context` alive so its data_ptr stays unique
+        if hit is None:
+            if len(self._ctx_cache) >= 8:
+                self._ctx_cache.pop(next(iter(self._ctx_cache)))
+                self.generation += 1             # a captured graph may have been reading the evicted tensors
+            self._ctx_cache[key] = {"version": context._version, "kv": kv}
+        else:
+            hit["version"] = context._version
+        return kv
+
+    def prepare_context(self, context, T):
+        """Project (or refresh in place) the context K/V outside of a captured step; returns the token a sampler compares
+        before replaying a graph: it changes whenever pointers the graph baked in may have been invalidated."""
+        P = self._packed or self._pack()
+        kv = self._context_kv(P, context, context.shape[0], T)
+        return (self.generation, kv[0].data_ptr())
 
     # ---- layer executors (all enqueue HIP kernels; tensors are token matrices [(b t) hw, C]) -------------
     def _res(self, e, L, h, emb_all, B, T, H, W):
@@ -384,7 +407,8 @@ class UNetModel(ParamTree):
         n1 = ops.layernorm(x, *blk["norm1"])
         qk = ops.linear(n1, blk["attn1.qk"])
         vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
-        att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125)
+        x3 = self.compute_dtype.x3
+        att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3)
         x = ops.linear(att, *blk["attn1.o"], residual=x)
         q = ops.linear(ops.layernorm(x, *blk["norm2"]), blk["attn2.q"])
         k_t, k_i, vt_t, vt_i, _ = kv
@@ -392,7 +416,7 @@ class UNetModel(ParamTree):
         sets = [(k_t[:, off:off + C_], vt_t[L.prefix].reshape(-1, 80), 77, T, C_ * 80)]
         if k_i is not None:
             sets.append((k_i[:, off:off + C_], vt_i[L.prefix], 16, 1, 16))
-        att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125)
+        att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
         x = self._ff(blk, x)
         return ops.linear(x, *e["out"], residual=h)
@@ -439,7 +463,7 @@ class UNetModel(ParamTree):
         assert C0 + C1 == self.in_channels, f"expected {self.in_channels} input channels, got {C0}+{C1}"
         if T > 16:
             raise NotImplementedError("temporal_length > 16 has no HIP path (configs/inference_geo4d.yaml:89)")
-        dt = self.compute_dtype
+        dt = self.storage_dtype
         inputs, middle, outputs, init_attn, _ = self.layout
         # embeddings (fp32, M = B rows)
         t_emb = ops.timestep_embedding(timesteps.to(torch.int64), P["freqs"])

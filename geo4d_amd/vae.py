@@ -131,6 +131,10 @@ class AutoencoderKL(ParamTree):
         self.invalidate()
         return self
 
+    @property
+    def storage_dtype(self):
+        return self.compute_dtype.storage
+
     def _apply(self, fn, *a, **k):
         self.invalidate()
         return super()._apply(fn, *a, **k)
@@ -155,7 +159,7 @@ class AutoencoderKL(ParamTree):
         wq[:zc, : self.embed_dim] = sd["post_quant_conv.weight"].reshape(zc, self.embed_dim)
         bq = torch.zeros((ka,), device=dev)
         bq[:zc] = sd["post_quant_conv.bias"]
-        P["pq"] = (wq.to(dt).contiguous(), bq.contiguous())
+        P["pq"] = (pack.cast(wq, dt), bq.contiguous())
         P["cpad"] = ka
         P["conv_in"] = (pack.pack_conv2d(sd["decoder.conv_in.weight"], dt, cin_pad=ka), f32("decoder.conv_in.bias"))
 
@@ -231,31 +235,46 @@ class AutoencoderKL(ParamTree):
         out, _, _ = ops.conv2d(a, *e["c2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip)
         return out
 
+    # fp32 score rows are materialised per chunk of frames (the batched GEMMs + row softmax below); the chunk is sized so the
+    # scratch stays under this many bytes whatever the resolution (N = 9216 at 576x1024 is 340 MB of scores per frame)
+    ATTN_SCRATCH_BYTES = 2 << 30
+
     def _attn(self, e, x, F_, H, W):
-        """Single-head attention over HW tokens with d = C (ae_modules.py:53-78) as batched MFMA GEMMs + fp32 row softmax."""
+        """Single-head attention over HW tokens with d = C (ae_modules.py:53-78) as batched MFMA GEMMs + fp32 row softmax,
+        a bounded number of frames at a time (it is ~1 % of the decoder's FLOPs and ~3 % of its time at every resolution of
+        BASELINE.json, so the d = 512 problem does not get its own flash kernel; the [N, N] scores never exceed the scratch)."""
         N, C_ = H * W, x.shape[1]
         dt = x.dtype
-        Np = (N + ops.k_align(dt) - 1) // ops.k_align(dt) * ops.k_align(dt)
+        x3 = self.compute_dtype.x3
+        ka = ops.k_align(self.compute_dtype)
+        Np = (N + ka - 1) // ka * ka
         hn = ops.groupnorm(x, *e["norm"], F=F_, HW=N, eps=1e-6)
         qk = ops.linear(hn, *e["qk"])                                             # [F*N, 2C]
-        scores = torch.empty((F_ * N, N), device=x.device, dtype=torch.float32)
-        ops.batched_gemm(qk[:, :C_], qk[:, C_:], scores, batch=F_, M=N, N=N, K=C_, a_bs=N * 2 * C_, b_bs=N * 2 * C_, o_bs=N * N,
-                         alpha=float(int(C_) ** -0.5))
-        probs = torch.zeros((F_ * N, Np), device=x.device, dtype=dt) if Np != N else torch.empty((F_ * N, N), device=x.device, dtype=dt)
-        ops._lib.check(ops._lib.load().geo4d_softmax_rows(scores.data_ptr(), N, probs.data_ptr(), Np, F_ * N, N, 1.0,
-                                                           ops.dt_code(dt), ops._stream()), "geo4d_softmax_rows")
         wv, bv = e["v"]
         vt = torch.zeros((F_ * C_, Np), device=x.device, dtype=dt) if Np != N else torch.empty((F_ * C_, N), device=x.device, dtype=dt)
         ops.batched_gemm(wv, hn, vt, batch=F_, M=C_, N=N, K=C_, a_bs=0, b_bs=N * C_, o_bs=C_ * Np, bias=bv, bias_per_row=True)
         o = torch.empty((F_ * N, C_), device=x.device, dtype=dt)
-        ops.batched_gemm(probs, vt, o, batch=F_, M=N, N=C_, K=Np, a_bs=N * Np, b_bs=C_ * Np, o_bs=N * C_)
+        esz = torch.empty((), dtype=dt).element_size()
+        fc = max(1, min(F_, int(self.ATTN_SCRATCH_BYTES // (N * (4 * N + esz * Np)))))
+        scores = torch.empty((fc * N, N), device=x.device, dtype=torch.float32)
+        probs = torch.zeros((fc * N, Np), device=x.device, dtype=dt) if Np != N else torch.empty((fc * N, N), device=x.device, dtype=dt)
+        lib = ops._lib.load()
+        for f0 in range(0, F_, fc):
+            nf = min(fc, F_ - f0)
+            qk_c = qk[f0 * N:(f0 + nf) * N]
+            ops.batched_gemm(qk_c[:, :C_], qk_c[:, C_:], scores, batch=nf, M=N, N=N, K=C_, a_bs=N * 2 * C_, b_bs=N * 2 * C_,
+                             o_bs=N * N, alpha=float(int(C_) ** -0.5), x3=x3)
+            ops._lib.check(lib.geo4d_softmax_rows(scores.data_ptr(), N, probs.data_ptr(), Np, nf * N, N, 1.0, ops.dt_code(dt),
+                                                  ops._stream()), "geo4d_softmax_rows")
+            ops.batched_gemm(probs, vt[f0 * C_:(f0 + nf) * C_], o[f0 * N:(f0 + nf) * N], batch=nf, M=N, N=C_, K=Np, a_bs=N * Np,
+                             b_bs=C_ * Np, o_bs=N * C_, x3=x3)
         return ops.linear(o, *e["o"], residual=x)
 
     def decoder_features(self, z):
         """z [n, 4, h, w] (already divided by scale_factor) -> feature tokens [n*H*W, feat_ch], H, W (pre norm_out)."""
         P = self._packed or self._pack()
         n, zc, H, W = z.shape
-        dt = self.compute_dtype
+        dt = self.storage_dtype
         x = ops.tokens_from_ncthw(z.float().reshape(n, zc, 1, H, W).contiguous(), None, P["cpad"], dt)
         x = ops.linear(x, *P["pq"])
         x, _, _ = ops.conv2d(x, *P["conv_in"], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1)
@@ -309,7 +328,7 @@ class AutoencoderKL(ParamTree):
         nlev = len(self.ddconfig["ch_mult"])
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise ValueError(f"encode: H, W must be multiples of {1 << (nlev - 1)} (got {H}x{W})")
-        dt = self.compute_dtype
+        dt = self.storage_dtype
         t = ops.tokens_from_ncthw(x.float().reshape(n, ci, 1, H, W).contiguous(), None, P["cpad"], dt)    # [n*H*W, cpad]
         if with_adaptor:
             if self.adaptorconfig is None:

@@ -10,6 +10,9 @@
  *     (a hipStream_t passed as void*), so every call is hipGraph-capturable;
  *   - activations are channels-last "tokens": row (b*T + t)*H*W + y*W + x, `ld*` = row pitch in ELEMENTS;
  *     dtype codes: 0 = f32 (exact parity mode, v_mfma_f32_32x32x2_f32), 1 = bf16, 2 = f16 (MFMA 32x32x16, fp32 acc);
+ *     3 = bf16x3 (conv_gemm / attention only): operands are f32 in memory (4 bytes per element, `ld*` in elements) and
+ *     are multiplied as bf16 hi + bf16 lo with three bf16 MFMAs per product (~16 mantissa bits at 1/3 of the bf16
+ *     rate instead of 1/16 for f32 MFMA) — the mode that meets the 1e-3 parity bar; every other entry point takes 0 for it;
  *   - every row pitch / base pointer must be 16-byte aligned (kernels move 16-byte chunks);
  *   - return 0 on success, negative errno-style code otherwise (-22 EINVAL, -95 ENOTSUP, -5 EIO = HIP launch
  *     error); geo4d_last_error() returns a thread-local message. Kernels never abort().
@@ -22,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEO4D_ABI_VERSION 1
+#define GEO4D_ABI_VERSION 2
 
 /* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
  * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
@@ -61,6 +64,8 @@ typedef struct geo4d_conv_gemm_t {
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
     int debug_ablate;    /* reserved (was a profiling knob): must be 0                   */
     float alpha;
+    int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
+                            [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);
 
