@@ -10,6 +10,9 @@ from .ddim import DDIMSampler
 from .ddim_multiplecond import DDIMSampler as DDIMSamplerMulticond
 
 
+DECODE_PIXEL_BUDGET = 30 * 1000 * 1000     # output pixels per decoder pass (decode_modalities)
+
+
 def window_slices(T, stride=4, length=16):
     """test_geo4d.py:417-423. The reference tests ``slice(T-16, T) not in slice_list`` against entries built as
     ``slice(start, start+16, 1)``; ``slice(a, b) != slice(a, b, 1)``, so the tail window is ALWAYS appended — and is a
@@ -44,26 +47,56 @@ def decode_modalities(model, samples, pointmap_vae=None):
     vae = model.first_stage_model
     pvae = pointmap_vae if pointmap_vae is not None else vae
     inv = 1.0 / model.scale_factor
-
-    def frames(z):
-        return (z.permute(0, 2, 1, 3, 4).reshape(b * t, 4, h, w) * inv).contiguous()
-
     H, W = 8 * h, 8 * w
     out = torch.empty((b, 11, t, H, W), device=samples.device, dtype=torch.float32)
-    # point map + confidence
-    feat, _, _ = pvae.decoder_features(frames(samples[:, 0:4]))
-    Pp = pvae._packed
-    pvae._head(Pp["head"], feat, b * t, H, W, out[:, 0:], t, 11)
-    pvae._head(Pp["adaptor_head"], pvae._conf(Pp, feat, b * t, H, W), b * t, H, W, out[:, 3:], t, 11)
-    # ray | cross | depth share the first-stage decoder: one 3*B*T-frame batch through the trunk
-    z3 = torch.cat([frames(samples[:, 4:8]), frames(samples[:, 8:12]), frames(samples[:, 12:16])], 0)
-    feat, _, _ = vae.decoder_features(z3)
-    Pv = vae._packed
-    n = b * t * H * W
-    vae._head(Pv["head"], feat[0:n], b * t, H, W, out[:, 4:], t, 11)
-    vae._head(Pv["head"], feat[n:2 * n], b * t, H, W, out[:, 7:], t, 11)
-    vae._head(Pv["head_mean"], feat[2 * n:3 * n], b * t, H, W, out[:, 10:], t, 11)
+    # clips per pass: the 3-modality batch of one pass holds 3 * cb * t frames of [H*W, 128] feature maps (7.5 GB per bf16 tensor
+    # at the budget): 16 x 320x512 -> all clips at once; 4 x 16 x 576x1024 (BASELINE configs[4]) -> one clip per pass
+    cb = max(1, min(b, DECODE_PIXEL_BUDGET // max(1, 3 * t * H * W)))
+    for b0 in range(0, b, cb):
+        s_, o_ = samples[b0:b0 + cb], out[b0:b0 + cb]
+        n = s_.shape[0]
+
+        def frames(z):
+            return (z.permute(0, 2, 1, 3, 4).reshape(n * t, 4, h, w) * inv).contiguous()
+
+        # point map + confidence
+        feat, _, _ = pvae.decoder_features(frames(s_[:, 0:4]))
+        Pp = pvae._packed
+        pvae._head(Pp["head"], feat, n * t, H, W, o_[:, 0:], t, 11)
+        pvae._head(Pp["adaptor_head"], pvae._conf(Pp, feat, n * t, H, W), n * t, H, W, o_[:, 3:], t, 11)
+        # ray | cross | depth share the first-stage decoder: one 3*n*t-frame batch through the trunk
+        z3 = torch.cat([frames(s_[:, 4:8]), frames(s_[:, 8:12]), frames(s_[:, 12:16])], 0)
+        feat, _, _ = vae.decoder_features(z3)
+        Pv = vae._packed
+        px = n * t * H * W
+        vae._head(Pv["head"], feat[0:px], n * t, H, W, o_[:, 4:], t, 11)
+        vae._head(Pv["head"], feat[px:2 * px], n * t, H, W, o_[:, 7:], t, 11)
+        vae._head(Pv["head_mean"], feat[2 * px:3 * px], n * t, H, W, o_[:, 10:], t, 11)
     return out
+
+
+@torch.no_grad()
+def decode_modalities_sharded(model, samples, pointmap_vae=None, rank=None, world=None, group=None, decoder=None):
+    """Frame-sharded 4-modality decode of ONE window whose latent every rank holds (north_star: "per-frame VAE decode ...
+    shard over the 8 GPUs ... RCCL all-gather ... to reassemble the clip"; the per-frame independence is ddpm3d.py:810-819):
+    rank r decodes frames ``dist.frame_shard(T, r, world)`` of all four modalities, one all-gather along the frame axis
+    returns [B, 11, T, H, W] on every rank. T = 16 on 8 GPUs = 2 frames (8 frame-modalities) per GPU."""
+    from . import dist as gdist
+    if world is None:
+        world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
+    if rank is None:
+        rank = torch.distributed.get_rank(group) if torch.distributed.is_initialized() else 0
+    decoder = decoder or decode_modalities
+    if world == 1:
+        return decoder(model, samples, pointmap_vae)
+    T = samples.shape[2]
+    lo, hi = gdist.frame_shard(T, rank, world)
+    if hi > lo:
+        part = decoder(model, samples[:, :, lo:hi].contiguous(), pointmap_vae)
+    else:                                         # more ranks than frames: this rank only takes part in the collective
+        b, _, _, h, w = samples.shape
+        part = samples.new_zeros((b, 11, 0, 8 * h, 8 * w), dtype=torch.float32)
+    return gdist.all_gather_frames(part, T, rank=rank, world=world, group=group, dim=2)
 
 
 @torch.no_grad()
@@ -76,11 +109,12 @@ def get_latent_z(model, videos):
 def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddim_steps=50, ddim_eta=1.,
                            unconditional_guidance_scale=1.0, cfg_img=None, fs=None, text_input=False,
                            multiple_cond_cfg=False, loop=False, interp=False, timestep_spacing='uniform',
-                           guidance_rescale=0.0, pointmap_vae=None, cond=None, x_T=None, **kwargs):
+                           guidance_rescale=0.0, pointmap_vae=None, cond=None, x_T=None, decode=True, **kwargs):
     """test_geo4d.py:118-274 for modality 'pc_ray_cross_depth'. ``cond`` = {"c_crossattn": [ctx [B,77+16T,1024]]} must be
     supplied (the OpenCLIP / Resampler front-end is N3); ``c_concat`` is taken from ``cond`` if present, otherwise computed
     from ``videos`` [B,3,T,H,W] by the VAE encoder like the reference does. ``multiple_cond_cfg`` selects the 3-way guidance
-    sampler. Returns [B, n_samples, 11, T, H, W] like the reference."""
+    sampler. Returns [B, n_samples, 11, T, H, W] like the reference; with ``decode=False`` the denoised latents
+    [B, n_samples, 16, T, h, w] instead (the caller decodes them, e.g. frame-sharded across GPUs)."""
     if loop or interp:
         raise NotImplementedError("loop / interp raise in the reference too (test_geo4d.py:161-162)")
     batch_size = noise_shape[0]
@@ -118,7 +152,7 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
                                     unconditional_guidance_scale=unconditional_guidance_scale, unconditional_conditioning=uc,
                                     eta=ddim_eta, cfg_img=cfg_img, mask=None, x0=None, fs=fs_t, x_T=x_T,
                                     timestep_spacing=timestep_spacing, guidance_rescale=guidance_rescale, **kwargs)
-        variants.append(decode_modalities(model, samples, pointmap_vae))
+        variants.append(decode_modalities(model, samples, pointmap_vae) if decode else samples)
     return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)
 
 
@@ -126,7 +160,7 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
 def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_length=16, seed=123, ddim_steps=50, ddim_eta=0.0,
              unconditional_guidance_scale=1.0, fs=24, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
              prompts=("Output a video that assigns each 3D location in the world a consistent color.",),
-             synthesize=None, gather=True, with_cameras=False, **kwargs):
+             synthesize=None, gather=True, with_cameras=False, decode="local", decoder=None, **kwargs):
     """The window loop of ``run_inference`` (test_geo4d.py:396-443), data-parallel over windows.
 
     ``videos_all`` [1,3,T,H,W] in [-1,1]; ``context`` = cross-attention context [1, 77+16*video_length, D] (the OpenCLIP /
@@ -138,7 +172,13 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
     device by ``geo4d_amd.rays``, no host sync in the loop). The initial noise, the posterior sampling of the VAE encode and
     (eta > 0) the per-step noise are all seeded PER WINDOW (``seed``, window index), so the result does not depend on the
     number of GPUs or on which windows a rank ran before — unlike the reference's single sequential RNG stream, which
-    cannot be reproduced across a sharded loop."""
+    cannot be reproduced across a sharded loop.
+
+    ``decode``: "local" — every rank decodes the windows it denoised and ONE all-gather of the decoded maps follows the loop;
+    "sharded" — windows are processed in rounds of ``world``; each round's latents are broadcast by their owners (2.6 MB each)
+    and every window's 4 x T frame-modalities are decoded FRAME-SHARDED over all ranks with an all-gather along the frame axis
+    (decode_modalities_sharded), which keeps all GPUs busy in a ragged last round (14 windows on 8 GPUs) and for a single window.
+    Every rank ends up with every window either way."""
     from . import dist as gdist
     synthesize = synthesize or image_guided_synthesis
     B, C, T, H, W = videos_all.shape
@@ -150,24 +190,52 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
     channels = model.model.diffusion_model.out_channels
     noise_shape = [B, channels, video_length, H // 8, W // 8]
     local, traj = [], []
-    for wi in gdist.shard_windows(len(slices), rank, world):
+
+    def cameras(maps):
+        from .rays import raymap_to_camera_matrix
+        return raymap_to_camera_matrix(maps[:, 4:7], maps[:, 7:10])[None]
+
+    def one_window(wi, decode_here):
         videos = videos_all[:, :, slices[wi]].clone()
         wseed = (int(seed) * 1000003 + wi) % (2 ** 63 - 1)
         x_T = torch.randn(noise_shape, generator=torch.Generator().manual_seed(wseed)).to(videos_all.device)
         if ddim_eta > 0.0 and videos_all.is_cuda:   # per-window device stream for the stochastic step noise (eta > 0)
             kwargs["noise_generator"] = torch.Generator(device=videos_all.device).manual_seed(wseed)
         ctx = context(videos) if callable(context) else context
+        extra = {} if decode_here else {"decode": False}
         with torch.random.fork_rng(devices=[]):
             torch.manual_seed(wseed)                                   # posterior sampling noise of the VAE encode
             maps = synthesize(model, list(prompts), videos, noise_shape, n_samples=1, ddim_steps=ddim_steps, ddim_eta=ddim_eta,
                               unconditional_guidance_scale=unconditional_guidance_scale, fs=fs, timestep_spacing=timestep_spacing,
                               guidance_rescale=guidance_rescale, pointmap_vae=pointmap_vae, cond={"c_crossattn": [ctx]},
-                              x_T=x_T, **kwargs)
+                              x_T=x_T, **extra, **kwargs)
         assert maps.shape[1] == 1, "only support variants size = 1"
-        local.append(maps[:, 0])
+        return maps[:, 0]
+
+    if decode == "sharded" and world > 1:
+        if B != 1:
+            raise ValueError("sharded decode handles one clip at a time")
+        nwin = len(slices)
+        for k in range(0, nwin, world):
+            lat = one_window(k + rank, False).float().contiguous() if k + rank < nwin else None
+            for wi in range(k, min(k + world, nwin)):
+                buf = lat if wi - k == rank else videos_all.new_empty(noise_shape, dtype=torch.float32)
+                gdist.broadcast_from(buf, wi - k)
+                maps = decode_modalities_sharded(model, buf, pointmap_vae, rank=rank, world=world, decoder=decoder)
+                local.append(maps)
+                if with_cameras:
+                    traj.append(cameras(maps))
+        out = [torch.cat(local, 0)]
         if with_cameras:
-            from .rays import raymap_to_camera_matrix
-            traj.append(raymap_to_camera_matrix(maps[:, 0, 4:7], maps[:, 0, 7:10])[None])
+            out.append(torch.cat(traj, 0))
+        return (slices, *out)
+    if decode not in ("local", "sharded"):
+        raise ValueError(f"run_clip: decode={decode!r} (expected 'local' or 'sharded')")
+    for wi in gdist.shard_windows(len(slices), rank, world):
+        maps = one_window(wi, True)
+        local.append(maps)
+        if with_cameras:
+            traj.append(cameras(maps))
     like = videos_all.new_zeros((0, 11, video_length, H, W), dtype=torch.float32)
     local = torch.cat(local, 0) if local else like
     out = [local]

@@ -23,6 +23,14 @@ def _worker(rank, world, port, num_windows, q):
     local = torch.stack([torch.full((3, 4), float(i)) for i in mine]) if mine else torch.zeros((0, 3, 4))
     full = gd.all_gather_windows(local, num_windows)
     ok = all(bool((full[i] == float(i)).all()) for i in range(num_windows)) and full.shape == (num_windows, 3, 4)
+    pending = gd.all_gather_windows(local, num_windows, async_op=True)       # the overlapped form used by bench.py
+    ok = ok and torch.equal(pending.wait(), full)
+    # frame-sharded decode reassembly: ragged frame slices (T = 5 over 2 ranks: 3 + 2)
+    T = 5
+    lo, hi = gd.frame_shard(T, r, w)
+    part = torch.arange(lo, hi, dtype=torch.float32).reshape(1, 1, hi - lo, 1).expand(2, 11, hi - lo, 3).contiguous()
+    frames = gd.all_gather_frames(part, T, dim=2)
+    ok = ok and frames.shape == (2, 11, T, 3) and bool((frames[0, 0, :, 0] == torch.arange(T, dtype=torch.float32)).all())
     q.put((rank, mine, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -41,13 +49,19 @@ def test_window_sharding_and_allgather_world2():
         assert res[0][2] and res[1][2]
 
 
-def _stub_synth(model, prompts, videos, noise_shape, n_samples=1, x_T=None, cond=None, **kw):
+def _stub_decoder(model, samples, pointmap_vae=None):
+    """Frame-independent stand-in for the 4-modality decode: [B,16,t,h,w] -> [B,11,t,8h,8w]."""
+    b, _, t, h, w = samples.shape
+    return samples.mean(dim=(1, 3, 4)).reshape(b, 1, t, 1, 1).expand(b, 11, t, 8 * h, 8 * w).contiguous()
+
+
+def _stub_synth(model, prompts, videos, noise_shape, n_samples=1, x_T=None, cond=None, decode=True, **kw):
     """Stands in for the HIP synthesis on CPU: a deterministic function of the window's frames, its noise and the CPU RNG
-    state run_clip seeds per window."""
+    state run_clip seeds per window. decode=False returns the 'latent' like image_guided_synthesis does."""
     B, _, T, h, w = noise_shape
-    v = videos.mean(dim=(1, 3, 4)).reshape(B, 1, 1, T, 1, 1)
-    out = torch.zeros((B, 1, 11, T, 8 * h, 8 * w)) + v + x_T.mean() + torch.randn(1) + cond["c_crossattn"][0].mean()
-    return out
+    v = videos.mean(dim=(1, 3, 4)).reshape(B, 1, T, 1, 1)
+    lat = torch.zeros((B, 16, T, h, w)) + v + x_T.mean() + torch.randn(1) + cond["c_crossattn"][0].mean()
+    return (_stub_decoder(model, lat) if decode else lat)[:, None]
 
 
 class _StubModel:
@@ -65,6 +79,9 @@ def _clip_worker(rank, world, port, q):
     gd.init_from_env(backend="gloo")
     video = torch.arange(1 * 3 * 22 * 16 * 16, dtype=torch.float32).reshape(1, 3, 22, 16, 16) / 1e4
     slices, maps = run_clip(_StubModel, video, torch.ones((1, 333, 8)), ddim_steps=2, synthesize=_stub_synth)
+    _, maps_sh = run_clip(_StubModel, video, torch.ones((1, 333, 8)), ddim_steps=2, synthesize=_stub_synth, decode="sharded",
+                          decoder=_stub_decoder)   # rounds of 2 windows, latents broadcast, frames decoded 8 + 8, gathered
+    assert torch.equal(maps, maps_sh), "frame-sharded decode mode differs from the local-decode mode"
     q.put((rank, [(s.start, s.stop) for s in slices], maps.numpy()))   # by value: a torch tensor would travel as a shared-memory fd
                                                                       # served by this process, which may have exited before the parent reads it
     dist.barrier()
@@ -90,7 +107,10 @@ def test_run_clip_world2_equals_world1():
 
 
 def test_shard_tables():
-    from geo4d_amd.dist import shard_windows, window_owner_table
+    from geo4d_amd.dist import frame_shard, shard_windows, window_owner_table
+    assert [frame_shard(16, r, 8) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]
+    assert [frame_shard(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [frame_shard(3, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]
     assert [len(shard_windows(30, r, 8)) for r in range(8)] == [4, 4, 4, 4, 4, 4, 3, 3]
     assert window_owner_table(14, 8) == ([2, 2, 2, 2, 2, 2, 1, 1], 2)
     assert sorted(sum((shard_windows(14, r, 8) for r in range(8)), [])) == list(range(14))

@@ -1,10 +1,12 @@
 """Parity of the HIP path (U-Net, DDIM sampler, VAE decode, 4-modality decode) against
  (a) golden outputs produced by the reference itself (tests/golden/*.pt, see generate.py) and
  (b) the oracle on further seeded inputs.
-Tolerances (relative L2 on the whole tensor), written per mode:
-   f32  (exact-f32 MFMA, parity mode)      : 1e-3 is the north-star bar on the point map; we assert 2e-4
-   f16  (fp32 accumulate)                   : 1e-2
-   bf16 (bench dtype, fp32 accumulate)      : 5e-2  (8-bit mantissa through ~150 layers; reported, not hidden)
+Tolerances (relative L2 on the whole tensor), written per mode. The north-star bar is 1e-3 on the point map:
+   f32    (exact-f32 MFMA)                                    : we assert 2e-4
+   bf16x3 (f32 storage, 3-term bf16 split MFMA; BENCH mode)   : we assert 2e-4 — the mode bench.py quotes meets the bar
+   f16    (single f16 pass, fp32 accumulate)                  : 1e-2   (fast mode, reported)
+   bf16   (single bf16 pass, fp32 accumulate)                 : 5e-2   (fast mode, reported: 8-bit mantissas through ~300 GEMMs)
+tests/precision_sim.py + tests/test_precision_floor.py show why no single 16-bit pass can meet 1e-3 on this network.
 """
 import os
 
@@ -19,7 +21,7 @@ from oracle.params import seeded_state_dict
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MODES = [("f32", 2e-4), ("f16", 1e-2), ("bf16", 5e-2)]
+MODES = [("f32", 2e-4), ("bf16x3", 2e-4), ("f16", 1e-2), ("bf16", 5e-2)]
 
 
 def load(name):
@@ -63,7 +65,7 @@ def test_unet_vs_reference_golden(dev, mode, tol, case):
     assert e < tol
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16x3", 2e-4), ("bf16", 5e-2)])
 def test_unet_full_config_vs_reference_golden(dev, mode, tol):
     """The shipped yaml config (1.44 B parameters) against the reference UNetModel's own output."""
     g = load("unet_full.pt")
@@ -130,7 +132,7 @@ def _diffusion(dev, mode):
     return m.to(dev), u, v
 
 
-@pytest.mark.parametrize("mode,tol,graph", [("f32", 2e-4, False), ("f32", 2e-4, True), ("bf16", 1e-1, True)])
+@pytest.mark.parametrize("mode,tol,graph", [("f32", 2e-4, False), ("f32", 2e-4, True), ("bf16x3", 2e-4, True), ("bf16", 1e-1, True)])
 def test_ddim_sampler_vs_reference_golden(dev, mode, tol, graph):
     """Same call as test_geo4d.py:212-227; golden = reference DDIMSampler + LatentDiffusion.apply_model, S=4, eta 0."""
     from geo4d_amd.ddim import DDIMSampler
@@ -152,10 +154,11 @@ def test_ddim_sampler_vs_reference_golden(dev, mode, tol, graph):
     assert ray.shape == g["decode_first_stage_4_8"].shape and e2 < max(tol, 2e-4) * 2
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("f16", 2e-2), ("bf16", 1e-1)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("f16", 2e-2), ("bf16", 1e-1)])
 def test_window_end_to_end_vs_oracle(dev, mode, tol):
     """One window: DDIM (S=3, eta 0, uniform_trailing) + 4-modality decode, HIP vs oracle on identical inputs.
-    North-star bar: point-map relative L2 <= 1e-3 (asserted in f32 parity mode; reported for f16 / bf16)."""
+    North-star bar: point-map relative L2 <= 1e-3 — asserted, un-loosened, for the exact f32 mode AND for bf16x3, the mode
+    bench.py quotes its number in; f16 / bf16 are the reported fast modes."""
     from geo4d_amd.pipeline import image_guided_synthesis, postprocess_window
     from geo4d_amd.vae import AutoencoderKL
     m, u, v = _diffusion(dev, mode)
@@ -184,7 +187,7 @@ def test_window_end_to_end_vs_oracle(dev, mode, tol):
     e_pts, e_all = rel(got[:, 0:3], ref[:, 0:3]), rel(got, ref)
     print(f"[window e2e] mode={mode} point-map rel_l2 = {e_pts:.3e}  all 11 channels = {e_all:.3e} (tol {tol:.0e})")
     assert e_pts < tol and e_all < tol * 2
-    if mode == "f32":
+    if mode in ("f32", "bf16x3"):
         po, pr = postprocess_window(out[:, 0]), opipe.postprocess_window(ref)
         flips = (po["valid"].cpu() != ~pr["invalid"]).float().mean().item()
         assert flips < 1e-3 and rel(po["inverse_depthmap"], pr["inverse_depthmap"]) < 1e-3
@@ -398,3 +401,32 @@ def test_stochastic_ddim_runs(dev):
     out, _ = DDIMSampler(m).sample(S=3, conditioning=cond, batch_size=B, shape=[16, T, h, w], verbose=False, eta=1.0,
                                    fs=torch.tensor([24], device=dev), timestep_spacing="uniform_trailing")
     assert out.shape == (B, 16, T, h, w) and torch.isfinite(out).all()
+
+
+def test_rccl_path_executes_on_one_gpu(dev):
+    """The `nccl` (= RCCL) code path of geo4d_amd.dist on a world-size-1 group: init, the window all-gather (sync + async) and the
+    frame all-gather really call ncclAllGather on device tensors (the 8-GPU run is the driver's; multi-rank logic is covered
+    by the gloo world-2 tests in tests/test_dist_cpu.py)."""
+    import socket
+    import torch.distributed as dist
+    from geo4d_amd import dist as gd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        maps = torch.randn((2, 11, 4, 16, 24), device=dev)
+        full = gd.all_gather_windows(maps, 2, force=True)
+        pend = gd.all_gather_windows(maps, 2, async_op=True, force=True)
+        frames = gd.all_gather_frames(maps, 4, dim=2, force=True)
+        pf = gd.all_gather_frames(maps, 4, dim=2, async_op=True, force=True)
+        torch.cuda.synchronize()
+        assert torch.equal(full, maps) and torch.equal(pend.wait(), maps) and torch.equal(frames, maps) and torch.equal(pf.wait(), maps)
+        t = torch.ones(3, device=dev)
+        dist.all_reduce(t)
+        assert t.tolist() == [1.0, 1.0, 1.0]
+    finally:
+        dist.destroy_process_group()
