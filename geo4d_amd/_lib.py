@@ -57,7 +57,7 @@ class Attention(C.Structure):
         ("ldq", C.c_long), ("ldo", C.c_long), ("ldk", C.c_long * 2), ("ldvt", C.c_long * 2), ("vt_bs", C.c_long * 2),
         ("Nk", C.c_int * 2), ("kv_div", C.c_int * 2),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("nseg", C.c_int), ("head_dim", C.c_int), ("dtype", C.c_int),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("variant", C.c_int),
     ]
 
 

@@ -25,8 +25,10 @@ namespace {
 // K tiles are [64 keys][64 d] and V^T tiles [64 d][64 keys]: both are 64 rows of 16-byte slots filled by LDS-DMA
 // (lane-linear image), XOR-swizzled on the source side (128-byte rows: slot = chunk ^ ((row >> 1) & 7) as in gemm.hip;
 // 256-byte f32 rows: slot = chunk ^ (row & 15)).
-template <typename T, int NSEG>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t p) {
+// QB = 32-row query blocks per wave (1: 128 query rows per workgroup; 2: 256 — every K / V^T fragment read from LDS feeds
+// two MFMAs, and a launch needs half as many wave-slots). OCC = waves per SIMD the register allocator must leave room for.
+template <typename T, int NSEG, int QB, int OCC>
+__global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attention_t p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = (int)sizeof(T);
     constexpr int SLOTS = 64 / EPC;               // 16-byte slots per 64-element row: 8 (16-bit) or 16 (f32)
@@ -35,50 +37,59 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
     constexpr int TILE = 64 * ROWB;               // one operand tile
     constexpr int NDMA = TILE / 1024 / 4;         // DMA instructions per wave per operand: 2 / 4
     constexpr int RPI = 1024 / ROWB;              // rows per DMA instruction: 8 / 4
-    constexpr int PCH = IsX3<T>::value ? 2 : 16 / EPC;   // P chunks per 32-key block (x3: 16 keys per bf16 MFMA step, like the 16-bit types)
+    constexpr bool X3 = IsX3<T>::value;           // f32 storage, bf16 hi/lo split in registers, 3 bf16 MFMAs per product
+    constexpr int PCH = X3 ? 2 : 16 / EPC;        // P chunks per 32-key block (x3: 16 keys per bf16 MFMA step, like the 16-bit types)
+    constexpr int NQ = X3 ? 4 : NKK;              // MFMA k-steps over d = 64 (16 per step for the bf16 MFMA of the x3 path)
+    static_assert(QB == 1 || NSEG == 1, "two query blocks per wave are built for single-segment (self) attention only");
     __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];   // [buf][K | Vt]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int qrow = blockIdx.x * 128 + wave * 32 + li;
-    const bool qok = qrow < p.Nq;
     const T* __restrict__ Z = (const T*)p.zeros;
 
-    constexpr bool X3 = IsX3<T>::value;        // f32 storage, bf16 hi/lo split in registers, 3 bf16 MFMAs per product
-    constexpr int NQ = X3 ? 4 : NKK;              // MFMA k-steps over d = 64 (16 per step for the bf16 MFMA of the x3 path)
-    u32x4 qf[NQ], ql[X3 ? 4 : 1];                 // x3: qf = hi parts, ql = lo parts
-    {
-        const T* qp = (const T*)p.q + ((long)b * p.Nq + (qok ? qrow : 0)) * p.ldq + h * 64;
+    int qrow[QB];
+    bool qok[QB];
+    u32x4 qf[QB][NQ], ql[QB][X3 ? 4 : 1];         // x3: qf = hi parts, ql = lo parts
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        qrow[qb] = blockIdx.x * (128 * QB) + wave * (32 * QB) + qb * 32 + li;
+        qok[qb] = qrow[qb] < p.Nq;
+        const T* qp = (const T*)p.q + ((long)b * p.Nq + (qok[qb] ? qrow[qb] : 0)) * p.ldq + h * 64;
         if constexpr (X3) {
             // k-step s2 covers d = 16 s2 .. +16; lane (li, g) owns d = 16 s2 + 8 g .. +8 = f32 chunks 4 s2 + 2 g, + 1
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
                 u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
-                if (qok) {
+                if (qok[qb]) {
                     c0 = *(const u32x4*)(qp + (4 * s2 + 2 * g) * EPC);
                     c1 = *(const u32x4*)(qp + (4 * s2 + 2 * g + 1) * EPC);
                 }
-                split8_bf16(c0, c1, qf[s2], ql[s2]);
+                split8_bf16(c0, c1, qf[qb][s2], ql[qb][s2]);
             }
         } else {
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (qok) v = *(const u32x4*)(qp + (2 * kk + g) * EPC);
-                qf[kk] = v;
+                if (qok[qb]) v = *(const u32x4*)(qp + (2 * kk + g) * EPC);
+                qf[qb][kk] = v;
             }
         }
     }
-    f32x16 of[NSEG == 1 ? 1 : 2], oa[2];        // `of` (sum over segments) only exists for the dual-KV cross attention
+    f32x16 of[NSEG == 1 ? 1 : 2], oa[QB][2];    // `of` (sum over segments) only exists for the dual-KV cross attention (QB = 1)
+    float m_run[QB], l_run[QB];                 // running max of RAW scores; sums of exp2((s - m) * c)
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY;
+        l_run[qb] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            oa[d][r] = 0.f;
-            if constexpr (NSEG > 1) of[d][r] = 0.f;
-        }
-    float m_run = -INFINITY, l_run = 0.f;       // running max of RAW scores; sums of exp2((s - m) * c)
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                oa[qb][d][r] = 0.f;
+                if constexpr (NSEG > 1) of[d][r] = 0.f;
+            }
+    }
     const float c2 = p.scale * 1.4426950408889634f;
     // lazy rescale (defer-max): the running max is only raised when some row's tile max exceeds it by more than THR raw
     // units, i.e. P = exp2((s - m) * c2) is allowed to reach 2^6 — exact in fp32, same relative precision in bf16/f16.
@@ -150,74 +161,80 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
         const char* ktile = lds + buf * 2 * TILE;
         const char* vtile = ktile + TILE;
 
-        // ---- S^T = K.Q^T --------------------------------------------------------------------
-        f32x16 st[2];
+        // ---- S^T = K.Q^T: every K fragment is read once and multiplied with the Q fragments of all QB query blocks ----------
+        f32x16 st[QB][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[qb][kb][r] = 0.f;
+            const char* krow_ = ktile + (kb * 32 + li) * ROWB;
             if constexpr (X3) {
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
-                    const char* krow_ = ktile + (kb * 32 + li) * ROWB;
                     const u32x4 c0 = *(const u32x4*)(krow_ + (((4 * s2 + 2 * g) ^ swz) << 4));
                     const u32x4 c1 = *(const u32x4*)(krow_ + (((4 * s2 + 2 * g + 1) ^ swz) << 4));
                     u32x4 kh, kl;
                     split8_bf16(c0, c1, kh, kl);
-                    mma_x3(st[kb], kh, kl, qf[s2], ql[s2]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) mma_x3(st[qb][kb], kh, kl, qf[qb][s2], ql[qb][s2]);
                 }
             } else {
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
-                    const u32x4 a = *(const u32x4*)(ktile + (kb * 32 + li) * ROWB + (((2 * kk + g) ^ swz) << 4));
-                    cmma<T>(st[kb], a, qf[kk]);
+                    const u32x4 a = *(const u32x4*)(krow_ + (((2 * kk + g) ^ swz) << 4));
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) cmma<T>(st[qb][kb], a, qf[qb][kk]);
                 }
             }
         }
         // ---- online softmax on raw scores; exp2 with the scale folded in ----------------------
-        if (tile * 64 + 64 > nk) {               // only a ragged last tile pays for masking (wave-uniform branch)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (tile * 64 + 64 > nk) {               // only a ragged last tile pays for masking (wave-uniform branch)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (tile * 64 + kb * 32 + acc_row(r, g) >= nk) st[qb][kb][r] = -INFINITY;
+            }
+            float mt = st[qb][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; r += 2)          // v_max3_f32: 2 new values per instruction, no canonicalising v_max pairs
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[qb][0][r]), "v"(st[qb][0][r + 1 < 16 ? r + 1 : r]));
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[qb][1][r]), "v"(st[qb][1][r + 1]));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            if (__any(mt > m_run[qb] + thr)) {
+                const float m_new = fmaxf(m_run[qb], mt);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c2);   // m_run = -inf on the first tile -> 0
+                l_run[qb] *= alpha;
+                m_run[qb] = m_new;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oa[qb][d][r] *= alpha;
+            }
+            const f32x2 c2v = {c2, c2};
+            const f32x2 mcv = {-m_run[qb] * c2, -m_run[qb] * c2};
+            f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (tile * 64 + kb * 32 + acc_row(r, g) >= nk) st[kb][r] = -INFINITY;
+                for (int r = 0; r < 16; r += 2) {     // v_pk_fma_f32 + 2 x raw v_exp_f32 + v_pk_add_f32 per pair
+                    f32x2 x = {st[qb][kb][r], st[qb][kb][r + 1]};
+                    x = __builtin_elementwise_fma(x, c2v, mcv);
+                    x[0] = __builtin_amdgcn_exp2f(x[0]);
+                    x[1] = __builtin_amdgcn_exp2f(x[1]);
+                    st[qb][kb][r] = x[0];
+                    st[qb][kb][r + 1] = x[1];
+                    ls2 += x;
+                }
+            l_run[qb] += ls2[0] + ls2[1];
         }
-        float mt = st[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; r += 2)          // v_max3_f32: 2 new values per instruction, no canonicalising v_max pairs
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[0][r]), "v"(st[0][r + 1 < 16 ? r + 1 : r]));
-#pragma unroll
-        for (int r = 0; r < 16; r += 2)
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[1][r]), "v"(st[1][r + 1]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        if (__any(mt > m_run + thr)) {
-            const float m_new = fmaxf(m_run, mt);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);   // m_run = -inf on the first tile -> 0
-            l_run *= alpha;
-            m_run = m_new;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oa[d][r] *= alpha;
-        }
-        const f32x2 c2v = {c2, c2};
-        const f32x2 mcv = {-m_run * c2, -m_run * c2};
-        f32x2 ls2 = {0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {     // v_pk_fma_f32 + 2 x raw v_exp_f32 + v_pk_add_f32 per pair
-                f32x2 x = {st[kb][r], st[kb][r + 1]};
-                x = __builtin_elementwise_fma(x, c2v, mcv);
-                x[0] = __builtin_amdgcn_exp2f(x[0]);
-                x[1] = __builtin_amdgcn_exp2f(x[1]);
-                st[kb][r] = x[0];
-                st[kb][r + 1] = x[1];
-                ls2 += x;
-            }
-        const float ls = ls2[0] + ls2[1];
-        l_run += ls;
-        // ---- O^T += V^T.P^T -------------------------------------------------------------------
+        // ---- O^T += V^T.P^T: every V^T fragment is read once for all QB query blocks --------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -225,11 +242,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
                 if constexpr (X3) {
                     // P registers 8c .. 8c+7 of this lane = keys 32 kb + 16 c + 4 g + {0..3} and + 8 (see acc_row): split them once,
                     // fetch the same keys of V^T (f32 chunks 8 kb + 4 c + g and + 2) per 32-channel block and split those
-                    float pv[8];
+                    u32x4 ph[QB], pl[QB];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pv[j] = st[kb][c * 8 + j];
-                    u32x4 ph, pl;
-                    split8_bf16(pv, ph, pl);
+                    for (int qb = 0; qb < QB; ++qb) {
+                        float pv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pv[j] = st[qb][kb][c * 8 + j];
+                        split8_bf16(pv, ph[qb], pl[qb]);
+                    }
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
                         const char* vrow = vtile + (d * 32 + li) * ROWB;
@@ -237,13 +257,18 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
                         const u32x4 c1 = *(const u32x4*)(vrow + (((8 * kb + 4 * c + 2 + g) ^ swz) << 4));
                         u32x4 vh, vl;
                         split8_bf16(c0, c1, vh, vl);
-                        mma_x3(oa[d], vh, vl, ph, pl);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) mma_x3(oa[qb][d], vh, vl, ph[qb], pl[qb]);
                     }
                 } else {
-                    float pv[EPC];
+                    u32x4 bch[QB];
 #pragma unroll
-                    for (int j = 0; j < EPC; ++j) pv[j] = st[kb][c * EPC + j];
-                    const u32x4 bch = f32_to_chunk<T>(pv);
+                    for (int qb = 0; qb < QB; ++qb) {
+                        float pv[EPC];
+#pragma unroll
+                        for (int j = 0; j < EPC; ++j) pv[j] = st[qb][kb][c * EPC + j];
+                        bch[qb] = f32_to_chunk<T>(pv);
+                    }
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
                         u32x4 a;
@@ -257,50 +282,58 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const geo4d_attention_t
                             // keys kb*32 + 8c + 4g + {0..3}: slot 8kb + 2c + g
                             a = *(const u32x4*)(vrow + (((8 * kb + 2 * c + g) ^ swz) << 4));
                         }
-                        cmma<T>(oa[d], a, bch);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) cmma<T>(oa[qb][d], a, bch[qb]);
                     }
                 }
             }
         // ---- segment end: normalise and fold into the summed output ---------------------------
         if (ntile2 == 0) {
-            const float lt = l_run + __shfl_xor(l_run, 32);
-            const float inv = 1.0f / lt;
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+            for (int qb = 0; qb < QB; ++qb) {
+                const float lt = l_run[qb] + __shfl_xor(l_run[qb], 32);
+                const float inv = 1.0f / lt;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if constexpr (NSEG > 1) { of[d][r] += oa[d][r] * inv; oa[d][r] = 0.f; }
-                    else oa[d][r] *= inv;
-                }
-            m_run = -INFINITY;
-            l_run = 0.f;
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if constexpr (NSEG > 1) { of[d][r] += oa[qb][d][r] * inv; oa[qb][d][r] = 0.f; }
+                        else oa[qb][d][r] *= inv;
+                    }
+                m_run[qb] = -INFINITY;
+                l_run[qb] = 0.f;
+            }
         }
         if (!has_next) break;
         seg = nseg2;
         tile = ntile2;
         buf ^= 1;
     }
-    if (qok) {
-        T* op = (T*)p.o + ((long)b * p.Nq + qrow) * p.ldo + h * 64;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb) {
+        if (!qok[qb]) continue;
+        T* op = (T*)p.o + ((long)b * p.Nq + qrow[qb]) * p.ldo + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const f32x16& res = NSEG > 1 ? of[d % (NSEG == 1 ? 1 : 2)] : oa[qb][d];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int dcol = d * 32 + 8 * i + 4 * g;
                 if constexpr (ES == 2) {
                     float e[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { e[j] = (NSEG > 1 ? of[d % (NSEG == 1 ? 1 : 2)] : oa[d])[4 * i + j]; e[4 + j] = 0.f; }
+                    for (int j = 0; j < 4; ++j) { e[j] = res[4 * i + j]; e[4 + j] = 0.f; }
                     const u32x4 c = f32_to_chunk<T>(e);
                     u32x2 o2; o2[0] = c[0]; o2[1] = c[1];
                     *(u32x2*)(op + dcol) = o2;
                 } else {
                     float e[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) e[j] = (NSEG > 1 ? of[d % (NSEG == 1 ? 1 : 2)] : oa[d])[4 * i + j];
+                    for (int j = 0; j < 4; ++j) e[j] = res[4 * i + j];
                     *(u32x4*)(op + dcol) = f32_to_chunk<T>(e);
                 }
             }
+        }
     }
 }
 
@@ -424,23 +457,39 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     }
     if (!p.zeros || ((uintptr_t)p.zeros % 16)) { geo4d_set_error("attention: `zeros` must point at 16 zero bytes"); return GEO4D_EINVAL; }
     if (p.H > 65535 || p.B > 65535) { geo4d_set_error("attention: grid too large"); return GEO4D_EINVAL; }
-    const dim3 grid((p.Nq + 127) / 128, p.H, p.B);
     hipStream_t st = (hipStream_t)stream;
-    if (p.nseg == 1) {
-        switch (p.dtype) {
-            case GEO4D_F32: hipLaunchKernelGGL((flash_attn_kernel<float, 1>), grid, dim3(256), 0, st, p); break;
-            case GEO4D_BF16: hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, p); break;
-            case GEO4D_BF16X3: hipLaunchKernelGGL((flash_attn_kernel<bf16x3_t, 1>), grid, dim3(256), 0, st, p); break;
-            default: hipLaunchKernelGGL((flash_attn_kernel<f16_t, 1>), grid, dim3(256), 0, st, p); break;
-        }
-    } else {
-        switch (p.dtype) {
-            case GEO4D_F32: hipLaunchKernelGGL((flash_attn_kernel<float, 2>), grid, dim3(256), 0, st, p); break;
-            case GEO4D_BF16: hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 2>), grid, dim3(256), 0, st, p); break;
-            case GEO4D_BF16X3: hipLaunchKernelGGL((flash_attn_kernel<bf16x3_t, 2>), grid, dim3(256), 0, st, p); break;
-            default: hipLaunchKernelGGL((flash_attn_kernel<f16_t, 2>), grid, dim3(256), 0, st, p); break;
-        }
+    // variant: 0 = host default; explicit: 1 = 128 rows / workgroup at 3 waves per SIMD (round-1 kernel), 2 = the same at 4 waves
+    // per SIMD (128-VGPR budget), 3 = 256 rows / workgroup, two query blocks per wave (self-attention only)
+    int variant = p.variant;
+    if (variant < 0 || variant > 3) { geo4d_set_error("attention: unknown variant"); return GEO4D_EINVAL; }
+    if (variant == 0) variant = 1;
+    if (p.nseg == 2 || p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3) {
+        if (variant == 3 && p.nseg == 2) variant = 1;     // dual-KV cross attention: one query block per wave
+        if (variant == 2 && (p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3)) variant = 1;   // 4-byte storage needs > 128 VGPRs
     }
+    const int rows = variant == 3 ? 256 : 128;
+    const dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
+#define ATT_LAUNCH(TT, NS, QB_, OCC_) hipLaunchKernelGGL((flash_attn_kernel<TT, NS, QB_, OCC_>), grid, dim3(256), 0, st, p)
+#define ATT_TYPED(TT)                                                        \
+    do {                                                                     \
+        if (p.nseg == 2) { ATT_LAUNCH(TT, 2, 1, 1); }                        \
+        else if (variant == 3) { ATT_LAUNCH(TT, 1, 2, 2); }                  \
+        else { ATT_LAUNCH(TT, 1, 1, 1); }                                    \
+    } while (0)
+    switch (p.dtype) {
+        case GEO4D_F32: ATT_TYPED(float); break;
+        case GEO4D_BF16X3: ATT_TYPED(bf16x3_t); break;
+        case GEO4D_BF16:
+            if (p.nseg == 1 && variant == 2) ATT_LAUNCH(bf16_t, 1, 1, 4);
+            else ATT_TYPED(bf16_t);
+            break;
+        default:
+            if (p.nseg == 1 && variant == 2) ATT_LAUNCH(f16_t, 1, 1, 4);
+            else ATT_TYPED(f16_t);
+            break;
+    }
+#undef ATT_TYPED
+#undef ATT_LAUNCH
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;
 }

@@ -295,7 +295,10 @@ def softmax_rows(x, scale, out_dtype):
     return out
 
 
-def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False):
+ATTN_VARIANT = int(_os.environ.get("GEO4D_ATTN_VARIANT", "0"))   # 0 = library default; 1..3 = A/B builds (include/geo4d_hip.h)
+
+
+def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False, variant=None):
     """q [B*Nq, >=H*64] view; kv = list of (k, vt, Nk, kv_div, vt_bs): k [(B/kv_div)*Nk, >=H*64] view, vt = V TRANSPOSED
     as a [>=H*64, ld] view (row = channel, column = key) whose batch b' starts vt_bs elements after batch b'-1."""
     lib = _lib.load()
@@ -314,6 +317,7 @@ def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False):
         assert q.dtype == torch.float32, "x3 attention runs on f32 q / k / v^T"
         code = BF16X3
     p.B, p.H, p.Nq, p.nseg, p.head_dim, p.dtype, p.scale = B, H, Nq, len(kv), 64, code, scale
+    p.variant = ATTN_VARIANT if variant is None else variant
     _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
     return out
 

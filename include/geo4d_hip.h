@@ -107,6 +107,8 @@ typedef struct geo4d_attention_t {
     int Nk[2], kv_div[2];
     int B, H, Nq, nseg, head_dim, dtype;
     float scale;
+    int variant;         /* 0 = default; A/B builds of the same math: 1 = 128 query rows per workgroup, 2 = the same compiled for
+                            4 waves per SIMD (16-bit types), 3 = 256 rows per workgroup, two query blocks per wave (nseg == 1) */
 } geo4d_attention_t;
 int geo4d_attention(const geo4d_attention_t* p, void* stream);
 

@@ -145,8 +145,9 @@ def _sdpa(q, k, v, scale):
     return torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v
 
 
+@pytest.mark.parametrize("variant", [1, 3])
 @pytest.mark.parametrize("N", [40, 200, 640, 2304])
-def test_attention_self(dev, N):
+def test_attention_self(dev, N, variant):
     from geo4d_amd import ops
     B, H = (3, 5) if N < 600 else (2, 2)
     C_ = H * 64
@@ -154,7 +155,7 @@ def test_attention_self(dev, N):
     Np = (N + 3) // 4 * 4
     vt = torch.zeros((B, C_, Np), device=dev)
     vt[:, :, :N] = qkv[:, 2 * C_:].reshape(B, N, C_).permute(0, 2, 1)
-    out = ops.attention(qkv[:, :C_], [(qkv[:, C_:2 * C_], vt.reshape(-1, Np), N, 1, C_ * Np)], B=B, H=H, Nq=N, scale=0.125, x3=True)
+    out = ops.attention(qkv[:, :C_], [(qkv[:, C_:2 * C_], vt.reshape(-1, Np), N, 1, C_ * Np)], B=B, H=H, Nq=N, scale=0.125, x3=True, variant=variant)
     f = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     ref = _sdpa(f[0], f[1], f[2], 0.125).permute(0, 2, 1, 3).reshape(B * N, C_)
     check(f"attn self N={N}", out, ref, scale=2.0)

@@ -238,6 +238,23 @@ def test_attention_self(dev, dtype, N):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("N", [200, 640, 2560])
+def test_attention_variants(dev, dtype, variant, N):
+    """The A/B builds of the flash kernel (geo4d_attention_t.variant: 4-waves-per-SIMD build, two query blocks per wave with
+    256-row workgroups — ragged N = 200 leaves one block half empty) compute the same attention."""
+    from geo4d_amd import ops
+    B, H = 2, 3
+    C_ = H * 64
+    qkv = rnd((B * N, 3 * C_), dev, dtype, 130 + N)
+    vt = torch.stack([_vt(qkv[b * N:(b + 1) * N, 2 * C_:], 1, N) for b in range(B)])      # [B, C, N]
+    out = ops.attention(qkv[:, :C_], [(qkv[:, C_:2 * C_], vt.reshape(-1, N), N, 1, C_ * N)], B=B, H=H, Nq=N, scale=0.125, variant=variant)
+    f = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = _sdpa(f[0], f[1], f[2], 0.125).permute(0, 2, 1, 3).reshape(B * N, C_)
+    check(f"attn variant {variant} N={N}", out, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_v_projected_transposed(dev, dtype):
     """linear_t writes V^T directly (operand-swapped GEMM): same numbers as projecting then transposing."""
     from geo4d_amd import ops

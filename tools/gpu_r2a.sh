@@ -15,7 +15,9 @@ echo "pytest rc=$?" >> $O/tests.log
 grep -E "^\[|passed|failed|rc=|Error|error" $O/tests.log | tail -60
 timeout 900 python bench.py --steps 2 --warmup 1 > $O/bench.json 2> $O/bench.err
 tail -c 3000 $O/bench.json
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o x3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o x3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
 ls -la $O/prof | head
 find $O/prof -name "*stats*" | head
+find $O/prof -type f -size +8M -delete
+du -sh $O
