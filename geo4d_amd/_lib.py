@@ -70,6 +70,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_int,
                                      C.c_void_p]),
+    "geo4d_softmax_rows_causal": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_int,
+                                            C.c_int, C.c_void_p]),
     "geo4d_attention": (C.c_int, [C.POINTER(Attention), C.c_void_p]),
     "geo4d_temporal_attention": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
                                            C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
@@ -86,6 +88,8 @@ SIGNATURES = {
     "geo4d_cfg_combine_workspace": (C.c_size_t, [C.c_int]),
     "geo4d_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "geo4d_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]),
     "geo4d_advance_index": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_gather_timestep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_plucker_cameras_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

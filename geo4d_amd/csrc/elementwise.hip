@@ -267,6 +267,37 @@ extern "C" int geo4d_gather_timestep(const int* idx, const long* table, long* ts
     return GEO4D_OK;
 }
 
+// ---- token embedding lookup + positional embedding (OpenCLIP text tower, condition.py:212-214) ----------------------------
+// out[(b n), :] = table[tokens[b][n], :] + pos[n, :]   (fp32 tables, output in the engine's storage dtype)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const long* __restrict__ tokens, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, T* __restrict__ out, long ldo, int n_ctx,
+                                                           int width, int vocab) {
+    const long row = blockIdx.x;
+    long tok = tokens[row];
+    if (tok < 0 || tok >= vocab) tok = 0;
+    const float* tr = table + tok * width;
+    const float* pr = pos + (row % n_ctx) * (long)width;
+    for (int c = threadIdx.x; c < width; c += 256) Elem<T>::st(out + row * ldo + c, tr[c] + pr[c]);
+}
+
+extern "C" int geo4d_embed_tokens(const long* tokens, const float* table, const float* pos, void* out, long ldo, long rows, int n_ctx,
+                                  int width, int vocab, int dtype, void* stream) {
+    if (!tokens || !table || !pos || !out || rows <= 0 || rows > 2147483647L || n_ctx <= 0 || width <= 0 || vocab <= 0 || dtype < 0 || dtype > 2) {
+        geo4d_set_error("embed_tokens: bad arguments");
+        return GEO4D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)rows);
+    switch (dtype) {
+        case GEO4D_F32: hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, dim3(256), 0, s, tokens, table, pos, (float*)out, ldo, n_ctx, width, vocab); break;
+        case GEO4D_BF16: hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, grid, dim3(256), 0, s, tokens, table, pos, (bf16_t*)out, ldo, n_ctx, width, vocab); break;
+        default: hipLaunchKernelGGL(embed_tokens_kernel<f16_t>, grid, dim3(256), 0, s, tokens, table, pos, (f16_t*)out, ldo, n_ctx, width, vocab); break;
+    }
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
 // ---- error string / version ------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 void geo4d_set_error(const char* msg) {

@@ -68,6 +68,14 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     if ((long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win > 2147483647L) { geo4d_set_error("conv_gemm: more than 2^31 input pixels"); return GEO4D_EINVAL; }
     if (p.ups != 1 && p.ups != 2) { geo4d_set_error("conv_gemm: ups must be 1 or 2"); return GEO4D_EINVAL; }
     if (p.act == 2 && (p.N % 64 || p.out_nchw || p.R)) { geo4d_set_error("conv_gemm: GEGLU needs N % 64 == 0, row-major output, no residual"); return GEO4D_EINVAL; }
+    if (p.act < 0 || p.act > 3) { geo4d_set_error("conv_gemm: act must be 0 (none), 1 (SiLU), 2 (GEGLU) or 3 (GELU)"); return GEO4D_EINVAL; }
+    if (p.act == 3) {   // GELU lives in the vectorised epilogue only (the scalar NCTHW / odd-shape path stays small enough to unroll)
+        const int oesz = p.out_dtype == GEO4D_F32 ? 4 : 2;
+        if (p.out_nchw || p.R || (p.N % 8) || ((p.ldo * oesz) % 16) || ((uintptr_t)p.O % 16) || ((p.o_bs * oesz) % 16)) {
+            geo4d_set_error("conv_gemm: GELU needs a row-major output with N % 8 == 0, 16-byte aligned rows and no residual");
+            return GEO4D_EINVAL;
+        }
+    }
     if (p.rowbias && p.rowbias_div <= 0) { geo4d_set_error("conv_gemm: rowbias_div"); return GEO4D_EINVAL; }
     if (p.batch > 65535) { geo4d_set_error("conv_gemm: batch too large"); return GEO4D_EINVAL; }
     if (!p.zeros || ((uintptr_t)p.zeros % 16)) { geo4d_set_error("conv_gemm: `zeros` must point at 16 zero bytes (16-byte aligned) in device memory"); return GEO4D_EINVAL; }

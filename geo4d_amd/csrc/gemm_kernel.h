@@ -403,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
                                     if (p.rowbias) v += p.rowbias[rboff + n + j];
                                 }
                                 if (p.act == 1) v = silu_f(v);
+                        else if (p.act == 3) v = gelu_erf_f(v);
                             }
                             o[j] = v;
                         }
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const geo4d_conv_gem
         if (p.bias && !p.bias_per_row) v += p.bias[n + j];
         if (p.rowbias) v += p.rowbias[rboff + n + j];
         if (p.act == 1) v = silu_f(v);
+                        else if (p.act == 3) v = gelu_erf_f(v);
         if (p.R) v += load_res(p.R, bz * p.r_bs + (long)m * p.ldr + n + j, p.out_dtype);
         store_out(p.O, bz * p.o_bs + (long)m * p.ldo + n + j, v, p.out_dtype);
     }

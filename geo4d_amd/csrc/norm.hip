@@ -241,11 +241,14 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
 // ---- row softmax: y = softmax(scale * x), x fp32, one workgroup per row --------------------
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
-                                                           int cols, float scale) {
+                                                           int cols_all, float scale, int causal_period) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const float* xr = x + (long)blockIdx.x * ldx;
     T* yr = y + (long)blockIdx.x * ldy;
+    // causal: row r of each `causal_period`-row score matrix sees columns 0 .. r; the masked tail is written as exact zeros
+    const int cols = causal_period > 0 ? min(cols_all, (int)(blockIdx.x % causal_period) + 1) : cols_all;
+    for (int c = cols + tid; c < cols_all; c += 256) Elem<T>::st(yr + c, 0.f);
     float m = -INFINITY;
     for (int c = tid; c < cols; c += 256) m = fmaxf(m, xr[c] * scale);
     m = wave_max(m);
@@ -346,15 +349,26 @@ extern "C" int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M
     }
 }
 
+static int softmax_rows_launch(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
+                               int causal_period, void* stream);
 extern "C" int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
                                   void* stream) {
+    return softmax_rows_launch(x, ldx, y, ldy, rows, cols, scale, out_dtype, 0, stream);
+}
+extern "C" int geo4d_softmax_rows_causal(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
+                                         int causal_period, void* stream) {
+    if (causal_period <= 0) { geo4d_set_error("softmax_rows_causal: causal_period must be positive"); return GEO4D_EINVAL; }
+    return softmax_rows_launch(x, ldx, y, ldy, rows, cols, scale, out_dtype, causal_period, stream);
+}
+static int softmax_rows_launch(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
+                               int causal_period, void* stream) {
     if (rows <= 0 || cols <= 0 || out_dtype < 0 || out_dtype > 2 || rows > 2147483647L) { geo4d_set_error("softmax_rows: bad arguments"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)rows);
     switch (out_dtype) {
-        case GEO4D_F32: hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, s, x, ldx, (float*)y, ldy, cols, scale); break;
-        case GEO4D_BF16: hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, (bf16_t*)y, ldy, cols, scale); break;
-        default: hipLaunchKernelGGL(softmax_rows_kernel<f16_t>, grid, dim3(256), 0, s, x, ldx, (f16_t*)y, ldy, cols, scale); break;
+        case GEO4D_F32: hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, s, x, ldx, (float*)y, ldy, cols, scale, causal_period); break;
+        case GEO4D_BF16: hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, (bf16_t*)y, ldy, cols, scale, causal_period); break;
+        default: hipLaunchKernelGGL(softmax_rows_kernel<f16_t>, grid, dim3(256), 0, s, x, ldx, (f16_t*)y, ldy, cols, scale, causal_period); break;
     }
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;

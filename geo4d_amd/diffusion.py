@@ -6,8 +6,10 @@ dynamic-rescale table (:585-590), ``apply_model`` (:1002-1017), ``DiffusionWrapp
 ``model.perframe_ae``, ``model.decode_first_stage`` ...) works unchanged. The ~2400 training / logging lines of the
 reference class are out of scope.
 
-The conditioning encoders (OpenCLIP text/image + Resampler, VAE encode) are SURVEY.md §8(f) N3: they are not instantiated;
-``get_learned_conditioning`` / ``embedder`` / ``encode_first_stage`` raise unless a caller injects precomputed tensors.
+The conditioning encoders of SURVEY.md §8(f) N3 — OpenCLIP text / image towers and the Resampler (geo4d_amd/encoders.py), next
+to the VAE encode — are built LAZILY on first use of ``cond_stage_model`` / ``embedder`` / ``image_proj_model`` (or by
+``build_frontend()``): together they are ~1 B parameters that the denoise + decode hot path never touches, and callers that
+inject precomputed ``cond`` tensors (bench.py, run_clip) never pay for them.
 """
 import numpy as np
 import torch
@@ -61,8 +63,7 @@ class LatentDiffusion(nn.Module):
         self.parameterization = parameterization
         self.model = DiffusionWrapper(unet_config, conditioning_key or "crossattn")
         self.first_stage_model = instantiate_from_config(first_stage_config) if first_stage_config is not None else None
-        self.cond_stage_model = None      # N3: OpenCLIP text encoder not built
-        self.cond_stage_config = cond_stage_config
+        self.cond_stage_config = cond_stage_config      # front-end modules are built lazily: see __getattr__ / build_frontend
         self.scale_factor, self.scale_by_std = scale_factor, scale_by_std
         self.use_dynamic_rescale, self.perframe_ae, self.encoder_type = use_dynamic_rescale, perframe_ae, encoder_type
         self.modality, self.uncond_type, self.channels, self.image_size = modality, uncond_type, channels, image_size
@@ -132,13 +133,33 @@ class LatentDiffusion(nn.Module):
 
     decode_core_confhead = decode_first_stage_confhead
 
-    # ---- conditioning front-end: N3 -----------------------------------------------------------------------------------
-    def _n3(self, what):
-        raise NotImplementedError(f"{what}: the OpenCLIP text/image encoders and the Resampler of the conditioning front-end are "
-                                  "SURVEY.md §8(f) N3 and are not built (VAE encode is); pass precomputed `cond` tensors instead")
+    # ---- conditioning front-end (N3): lazily built submodules with the reference's attribute names ---------------------------
+    _FRONTEND = {"cond_stage_model": "cond_stage_config", "embedder": "img_cond_stage_config", "image_proj_model": "image_proj_stage_config"}
+
+    def __getattr__(self, name):
+        if name in LatentDiffusion._FRONTEND and "_modules" in self.__dict__ and name not in self._modules:
+            self.build_frontend(only=name)
+            return self._modules[name]
+        return super().__getattr__(name)
+
+    def build_frontend(self, only=None):
+        """Instantiate ``cond_stage_model`` (text), ``embedder`` (image) and ``image_proj_model`` (Resampler) from their yaml
+        sections, in the U-Net's compute mode, on this model's device. Idempotent."""
+        unet = self.model.diffusion_model
+        for name, cfg_attr in LatentDiffusion._FRONTEND.items():
+            if (only is not None and name != only) or name in self._modules:
+                continue
+            cfg = getattr(self, cfg_attr, None)
+            if not isinstance(cfg, dict) or not str(cfg.get("target", "")).startswith("geo4d_amd."):
+                raise NotImplementedError(f"{name}: no geo4d_amd front-end configured ({cfg_attr} = {cfg!r}); pass precomputed `cond` tensors "
+                                          "or point the yaml section at geo4d_amd.encoders.*")
+            cfg = {"target": cfg["target"], "params": dict(cfg.get("params") or {}, compute_dtype=getattr(unet, "compute_dtype", None))}
+            self.add_module(name, instantiate_from_config(cfg).to(self.device))
+        return self
 
     def get_learned_conditioning(self, c):
-        self._n3("get_learned_conditioning")
+        """ddpm3d.py:640-651: prompts (or token ids) -> text context [B, 77, 1024]."""
+        return self.cond_stage_model.encode(c)
 
     def get_first_stage_encoding(self, encoder_posterior, noise=None):
         """ddpm3d.py:674-681: sample the posterior (or pass a tensor through) and apply scale_factor."""
@@ -177,11 +198,18 @@ class LatentDiffusion(nn.Module):
         """ddpm3d.py:775-798: the same through encoder_adaptor."""
         return self._encode(self.first_stage_model.encode_with_adaptor, x)
 
-    def embedder(self, x):
-        self._n3("embedder")
-
-    def image_proj_model(self, x):
-        self._n3("image_proj_model")
+    @torch.no_grad()
+    def context_for(self, prompts, image=None, frames=None):
+        """The cross-attention context of test_geo4d.py:118-158 for modality 'pc_ray_cross_depth': text tokens (77) followed by
+        the Resampler's image tokens (16 per frame). ``cross_attention`` False (the shipped setting): ONE zero image per sample ->
+        [B, 77 + 16*T, 1024]; True: every frame of ``frames`` [b, c, t, h, w] is embedded."""
+        if self.cross_attention:
+            b, c, t, h, w = frames.shape
+            emb = self.embedder(frames.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w))
+            img_emb = self.image_proj_model(emb.reshape(b, t, emb.shape[1], emb.shape[2]))
+        else:
+            img_emb = self.image_proj_model(self.embedder(torch.zeros_like(image)))
+        return torch.cat([self.get_learned_conditioning(prompts).to(img_emb.device), img_emb], dim=1)
 
     # ---- checkpoints (test_geo4d.py:54-81): reference keys model.diffusion_model.* / first_stage_model.* ---------
     def load_reference_state_dict(self, state_dict):

@@ -284,14 +284,21 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out
 
 
-def softmax_rows(x, scale, out_dtype):
+def softmax_rows(x, scale, out_dtype, out=None, causal_period=0):
+    """softmax(scale * x) per row of fp32 scores; `out` may be a wider zero-initialised buffer (K padding of the next GEMM);
+    `causal_period` > 0: row r only sees columns <= r % causal_period (text-transformer mask)."""
     lib = _lib.load()
     _dev(x, "x")
     assert x.dtype == torch.float32
     rows, cols = x.shape
-    out = torch.empty((rows, cols), device=x.device, dtype=out_dtype)
-    _lib.check(lib.geo4d_softmax_rows(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), rows, cols, scale,
-                                      dt_code(out_dtype), _stream()), "geo4d_softmax_rows")
+    if out is None:
+        out = torch.empty((rows, cols), device=x.device, dtype=out_dtype)
+    if causal_period:
+        _lib.check(lib.geo4d_softmax_rows_causal(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), rows, cols, scale,
+                                                 dt_code(out.dtype), causal_period, _stream()), "geo4d_softmax_rows_causal")
+    else:
+        _lib.check(lib.geo4d_softmax_rows(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), rows, cols, scale,
+                                          dt_code(out.dtype), _stream()), "geo4d_softmax_rows")
     return out
 
 
@@ -392,6 +399,18 @@ def timestep_embedding(t, freqs):
     out = torch.empty((B, 2 * half), device=t.device, dtype=torch.float32)
     _lib.check(lib.geo4d_timestep_embedding(t.data_ptr(), freqs.data_ptr(), out.data_ptr(), B, 2 * half, _stream()),
                "geo4d_timestep_embedding")
+    return out
+
+
+def embed_tokens(tokens, table, pos, dtype):
+    """tokens int64 [B, n_ctx] (device), table fp32 [vocab, W], pos fp32 [n_ctx, W] -> [B * n_ctx, W] of `dtype`."""
+    lib = _lib.load()
+    _dev(tokens, "tokens")
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and table.dtype == torch.float32 and pos.dtype == torch.float32
+    B, n = tokens.shape
+    out = torch.empty((B * n, table.shape[1]), device=tokens.device, dtype=dtype)
+    _lib.check(lib.geo4d_embed_tokens(tokens.data_ptr(), table.data_ptr(), pos.data_ptr(), out.data_ptr(), _ld(out), B * n, n,
+                                      table.shape[1], table.shape[0], dt_code(dtype), _stream()), "geo4d_embed_tokens")
     return out
 
 

@@ -110,8 +110,9 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
                            unconditional_guidance_scale=1.0, cfg_img=None, fs=None, text_input=False,
                            multiple_cond_cfg=False, loop=False, interp=False, timestep_spacing='uniform',
                            guidance_rescale=0.0, pointmap_vae=None, cond=None, x_T=None, decode=True, **kwargs):
-    """test_geo4d.py:118-274 for modality 'pc_ray_cross_depth'. ``cond`` = {"c_crossattn": [ctx [B,77+16T,1024]]} must be
-    supplied (the OpenCLIP / Resampler front-end is N3); ``c_concat`` is taken from ``cond`` if present, otherwise computed
+    """test_geo4d.py:118-274 for modality 'pc_ray_cross_depth'. ``cond`` = {"c_crossattn": [ctx [B,77+16T,1024]]} may be
+    supplied; otherwise it is computed like the reference does (OpenCLIP text tower on the prompts + Resampler over the OpenCLIP
+    image tokens of a zero image, geo4d_amd/encoders.py). ``c_concat`` is taken from ``cond`` if present, otherwise computed
     from ``videos`` [B,3,T,H,W] by the VAE encoder like the reference does. ``multiple_cond_cfg`` selects the 3-way guidance
     sampler. Returns [B, n_samples, 11, T, H, W] like the reference; with ``decode=False`` the denoised latents
     [B, n_samples, 16, T, h, w] instead (the caller decodes them, e.g. frame-sharded across GPUs)."""
@@ -120,7 +121,19 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
     batch_size = noise_shape[0]
     fs_t = torch.tensor([fs] * batch_size, dtype=torch.long, device=model.device)
     if cond is None:
-        model.get_learned_conditioning(prompts)       # raises: the OpenCLIP / Resampler front-end is N3
+        # test_geo4d.py:124-158: text prompts are blanked unless text_input; the image branch embeds a ZERO image unless
+        # model.cross_attention (then every frame). Built lazily from geo4d_amd.encoders and cached: constant across windows.
+        if not text_input:
+            prompts = [""] * batch_size
+        key = (tuple(prompts), bool(model.cross_attention), tuple(videos.shape) if model.cross_attention else tuple(videos.shape[-2:]))
+        cache = model.__dict__.setdefault("_geo4d_context_cache", {})
+        ctx = cache.get(key) if not model.cross_attention else None
+        if ctx is None:
+            ctx = model.context_for(prompts, image=videos[:, :, 0], frames=videos)
+            if not model.cross_attention:
+                cache.clear()
+                cache[key] = ctx
+        cond = {"c_crossattn": [ctx]}
     if "c_concat" not in cond and model.model.conditioning_key == "hybrid":
         cond = dict(cond, c_concat=[get_latent_z(model, videos)])       # test_geo4d.py:159-170 (modality != img_vidpc)
     def with_latent(c):

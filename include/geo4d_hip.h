@@ -51,7 +51,7 @@ typedef struct geo4d_conv_gemm_t {
     int KT, KH, KW, pt, ph, pw, stride, ups;
     int rowbias_div;
     int bias_per_row;
-    int act;             /* 0 none, 1 SiLU, 2 GEGLU (packed pairs of 32 columns)        */
+    int act;             /* 0 none, 1 SiLU, 2 GEGLU (packed pairs of 32 columns), 3 GELU (erf)   */
     int dtype;           /* A/W element type                                            */
     int out_dtype;       /* O/R element type                                            */
     int out_nchw;        /* 1: store O as [B][ldo][T][Hout*Wout] (ldo = channel count of the
@@ -92,6 +92,10 @@ int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M, int C, fl
 /* y = softmax(scale * x) per row, x fp32; replaces F.softmax in the VAE AttnBlock (ae_modules.py:66-68). */
 int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
                        void* stream);
+/* the same with a causal mask: row r attends to columns <= r % causal_period (the attn_mask of the OpenCLIP text transformer,
+ * condition.py:217-221; rows of several (batch, head) score matrices of `causal_period` rows each stacked). */
+int geo4d_softmax_rows_causal(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
+                              int causal_period, void* stream);
 
 /* Fused multi-head attention, d_head = 64, no mask, up to two key/value sets with independent softmaxes whose
  * outputs are summed. q rows: b*Nq + i, head h at columns [64h, 64h+64). K rows of set s: (b / kv_div[s])*Nk[s] + j.
@@ -147,6 +151,10 @@ int geo4d_ddim_step(float* x, const float* v, const float* noise, float* pred_x0
 size_t geo4d_cfg_combine_workspace(int B);
 int geo4d_cfg_combine(const float* e_c, const float* e_u, const float* e_i, float* out, int B, long n, float scale, float cfg_img,
                       float guidance_rescale, void* workspace, size_t workspace_bytes, void* stream);
+/* out[(b n)][:] = table[tokens[b][n]][:] + pos[n][:]; replaces token_embedding(text) + positional_embedding of the OpenCLIP text
+ * tower (condition.py:212-214). table [vocab][width], pos [n_ctx][width] fp32; rows = B * n_ctx; out-of-range ids read row 0. */
+int geo4d_embed_tokens(const long* tokens, const float* table, const float* pos, void* out, long ldo, long rows, int n_ctx,
+                       int width, int vocab, int dtype, void* stream);
 int geo4d_advance_index(int* idx, int delta, void* stream);
 /* ts[b] = table[*idx] for b < B: the per-step `ts = torch.full((b,), step)` of ddim.py:170, read from a device table so
  * the captured step graph is step-independent. */

@@ -209,3 +209,24 @@ def test_unet_full_config_matches_reference():
     sd = seeded_state_dict(g["shapes"])
     y = ounet.unet_forward(sd, g["unet_config"], g["x"], g["t"], g["context"], g["fs"])
     assert rel(y, g["out"]) < 5e-5
+
+
+def test_frontend_oracle_vs_reference_resampler_and_hf_clip():
+    """N3: oracle/clip.py vs (a) the reference Resampler class' own outputs and (b) HuggingFace transformers' CLIP text /
+    vision models run on the same open_clip-format weights (open_clip itself is not installed: the pin is on the architecture)."""
+    from oracle import clip as oclip
+    from oracle.params import seeded_state_dict
+    g = torch.load(os.path.join(G, "clip_tiny.pt"), weights_only=False)
+    r = g["resampler"]
+    sd = seeded_state_dict(r["shapes"])
+    y3 = oclip.resampler_forward(sd, r["x3"], r["cfg"]["heads"], r["cfg"]["num_queries"] * r["cfg"]["video_length"])
+    y4 = oclip.resampler_forward(sd, r["x4"], r["cfg"]["heads"], r["cfg"]["num_queries"], r["cfg"]["video_length"])
+    assert rel(y3, r["y3"]) < 1e-5 and rel(y4, r["y4"]) < 1e-5, (rel(y3, r["y3"]), rel(y4, r["y4"]))
+    c = g["clip"]
+    sd = seeded_state_dict({**c["text_shapes"], **c["vision_shapes"]})
+    tp = oclip.text_transformer_forward(sd, c["tokens"], c["text_heads"], layer="penultimate")
+    tl = oclip.text_transformer_forward(sd, c["tokens"], c["text_heads"], layer="last")
+    vt = oclip.vision_transformer_forward(sd, c["pixels"], c["vision_heads"], preprocess=False)
+    errs = (rel(tp, c["text_penultimate"]), rel(tl, c["text_last"]), rel(vt, c["vision_tokens"]))
+    print("frontend oracle vs HF", errs)
+    assert max(errs) < 1e-5, errs
