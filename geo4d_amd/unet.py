@@ -42,16 +42,26 @@ class ParamTree(nn.Module):
 
 
 def init_params_(module, seed=0):
-    """Deterministic default init (checkpoints overwrite it): weights N(0, 1/fan_in), norm gains 1, biases 0."""
+    """Deterministic default init (checkpoints overwrite it): weights N(0, 1/fan_in), norm gains 1, biases 0. The normals come
+    from ONE 4 Mi-sample draw that the tensors walk through cyclically (a 1.44 B-parameter model would otherwise spend minutes in
+    the scalar CPU generator before every test and bench run)."""
     g = torch.Generator().manual_seed(seed)
+    pool = torch.randn((1 << 22) + 8191, generator=g)
+    pos = 0
     for name, p in module.named_parameters():
         if p.is_meta:
             continue
         if p.dim() <= 1:
             p.data.fill_(1.0 if name.endswith("weight") else 0.0)
         else:
-            fan_in = p[0].numel()
-            p.data.copy_(torch.randn(p.shape, generator=g) / math.sqrt(fan_in))
+            n, scale = p.numel(), 1.0 / math.sqrt(p[0].numel())
+            flat = p.data.view(-1)
+            done = 0
+            while done < n:
+                m = min(n - done, pool.numel() - pos)
+                torch.mul(pool[pos:pos + m], scale, out=flat[done:done + m])
+                done += m
+                pos = (pos + m) % pool.numel()
 
 
 # ------------------------------------------------------------------------------------------------------

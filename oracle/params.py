@@ -8,9 +8,26 @@ import zlib
 import torch
 
 
+BIG = 1 << 21     # tensors above 2 Mi elements (only the shipped 1.44 B config has them) are tiled from a 1 Mi-sample draw
+
+
+def _randn(shape, g):
+    n = 1
+    for s in shape:
+        n *= s
+    if n <= BIG:
+        return torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    # the scalar CPU generator needs minutes for 1.44e9 samples: draw 2^20 normals and lay them end to end, each copy with its own
+    # sign (still a pure function of (name, shape); the per-tensor statistics are those of the draw)
+    base = torch.randn(1 << 20, generator=g, dtype=torch.float32)
+    reps = (n + base.numel() - 1) // base.numel()
+    signs = (torch.randint(0, 2, (reps, 1), generator=g).float() * 2 - 1)
+    return (base[None, :] * signs).reshape(-1)[:n].reshape(tuple(shape))
+
+
 def fill_tensor(name, shape, gain=1.0):
     g = torch.Generator(device="cpu").manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
-    t = torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    t = _randn(shape, g)
     if len(shape) <= 1:
         if name.endswith("weight"):      # norm gain
             return 1.0 + 0.1 * t

@@ -230,3 +230,30 @@ def test_frontend_oracle_vs_reference_resampler_and_hf_clip():
     errs = (rel(tp, c["text_penultimate"]), rel(tl, c["text_last"]), rel(vt, c["vision_tokens"]))
     print("frontend oracle vs HF", errs)
     assert max(errs) < 1e-5, errs
+
+
+def test_alignment_oracle_vs_reference_optimizer():
+    """N1: oracle/align.py vs the reference LightPointCloudGroupOptimizer run by tests/golden/generate.py align (only `roma`
+    substituted): loss and gradients at a seeded starting point, the parameters after the reference's own 40-iteration
+    global_alignment_loop (Adam, linear schedule), and the weighted window registration."""
+    from oracle import align as oalign
+    g = torch.load(os.path.join(G, "align_tiny.pt"), weights_only=False)
+    G_, S, H, W = g["pred"].shape[:4]
+    data = dict(pred=g["pred"].reshape(G_ * S, H * W, 3), conf=g["conf"].reshape(G_ * S, H * W), H=H, W=W,
+                e_all=torch.tensor([i for grp in g["groups"] for i in grp]))
+    kw = dict(temporal_smoothing_weight=g["kw"]["temporal_smoothing_weight"], translation_weight=g["kw"]["translation_weight"])
+    P = {k: v.clone().requires_grad_(True) for k, v in g["init"].items()}
+    loss = oalign.alignment_loss(P, data, **kw)
+    loss.backward()
+    assert abs(float(loss) - g["loss0"]) < 1e-5 * abs(g["loss0"]), (float(loss), g["loss0"])
+    for k in P:
+        assert rel(P[k].grad, g["grads"][k]) < 1e-4, (k, rel(P[k].grad, g["grads"][k]))
+    P = {k: v.clone().requires_grad_(True) for k, v in g["init"].items()}
+    hist = oalign.alignment_loop(P, data, g["niter"], lr=g["lr"], lr_min=g["lr_min"], schedule=g["schedule"], **kw)
+    assert hist[-1] < 0.3 * hist[0]
+    for k in P:
+        assert rel(P[k].detach(), g["after"][k]) < 2e-3, (k, rel(P[k].detach(), g["after"][k]))
+    r = g["registration"]
+    R, T, s = oalign.rigid_points_registration(g["pred"][1][:3].reshape(-1, 3), g["pred"][0][1:].reshape(-1, 3),
+                                               weights=(g["conf"][1][:3] * g["conf"][0][1:]).reshape(-1), compute_scaling=True)
+    assert torch.allclose(R, r["R"], atol=1e-5) and torch.allclose(T, r["T"], atol=1e-5) and abs(float(s) - float(r["s"])) < 1e-5

@@ -65,15 +65,18 @@ def test_unet_vs_reference_golden(dev, mode, tol, case):
     assert e < tol
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16x3", 2e-4), ("bf16", 5e-2)])
-def test_unet_full_config_vs_reference_golden(dev, mode, tol):
-    """The shipped yaml config (1.44 B parameters) against the reference UNetModel's own output."""
+def test_unet_full_config_vs_reference_golden(dev, full_engine):
+    """The shipped yaml config (1.44 B parameters) against the reference UNetModel's own output (8x8 latents; the 40x64 pin is
+    tests/test_fullsize_gpu.py). One shared model instance, every compute mode."""
     g = load("unet_full.pt")
-    m = build_unet(g["unet_config"], g["shapes"], dev, mode)
-    y = m(g["x"].to(dev), g["t"].to(dev), context=g["context"].to(dev), fs=g["fs"].to(dev))
-    e = rel(y, g["out"])
-    print(f"[unet full config] mode={mode} rel_l2 vs reference = {e:.3e} (tol {tol:.0e})")
-    assert e < tol
+    m = full_engine[0].model.diffusion_model
+    m.load_state_dict(seeded_state_dict(g["shapes"]), strict=True)
+    for mode, tol in (("f32", 2e-4), ("bf16x3", 2e-4), ("bf16", 5e-2)):
+        m.set_compute_dtype(mode)
+        y = m(g["x"].to(dev), g["t"].to(dev), context=g["context"].to(dev), fs=g["fs"].to(dev))
+        e = rel(y, g["out"])
+        print(f"[unet full config] mode={mode} rel_l2 vs reference = {e:.3e} (tol {tol:.0e})")
+        assert e < tol
 
 
 @pytest.mark.parametrize("mode,tol", MODES)

@@ -31,7 +31,8 @@ def test_unet_tiny_config_at_sintel_window_size_vs_oracle(dev):
     x = torch.randn((B, 20, T, h, w), generator=gen)
     ctx = torch.randn((B, 77 + 16 * T, g["unet_config"]["context_dim"]), generator=gen)
     t, fs = torch.tensor([601]), torch.tensor([24])
-    torch.set_num_threads(os.cpu_count() or 8)
+    from conftest import cpu_threads
+    cpu_threads()
     ref = ounet.unet_forward(sd, g["unet_config"], x, t, ctx, fs)
     m = UNetModel(**g["unet_config"], compute_dtype="f32")
     m.load_state_dict(sd, strict=True)
@@ -45,9 +46,10 @@ def test_unet_tiny_config_at_sintel_window_size_vs_oracle(dev):
 
 
 @pytest.fixture(scope="module")
-def engine(dev):
+def engine(dev, full_engine):
     import bench
-    return bench.build("f16", dev)
+    bench.set_mode(*full_engine, "f16")
+    return full_engine
 
 
 def test_full_config_at_576x1024_latents(engine, dev):
