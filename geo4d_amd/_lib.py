@@ -61,6 +61,18 @@ class Attention(C.Structure):
     ]
 
 
+class Align(C.Structure):
+    _fields_ = [
+        ("pred", C.c_void_p), ("conf", C.c_void_p), ("logdepth", C.c_void_p), ("cams", C.c_void_p), ("slot_trf", C.c_void_p),
+        ("slot_ptr", C.c_void_p), ("slot_idx", C.c_void_p),
+        ("grad_logdepth", C.c_void_p), ("img_sums", C.c_void_p), ("slot_sums", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("img_part", C.c_void_p), ("slot_part", C.c_void_p),
+        ("n_imgs", C.c_int), ("n_slots", C.c_int), ("H", C.c_int), ("W", C.c_int), ("chunk_pixels", C.c_int), ("max_slots_per_image", C.c_int),
+        ("conf_clamp", C.c_float), ("inv_area", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); checked against include/geo4d_hip.h by tests/test_host_logic.py::test_c_abi_exports_every_declared_symbol
 SIGNATURES = {
     "geo4d_conv_gemm": (C.c_int, [C.POINTER(ConvGemm), C.c_void_p]),
@@ -95,6 +107,10 @@ SIGNATURES = {
     "geo4d_plucker_cameras_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "geo4d_plucker_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                         C.c_size_t, C.c_void_p, C.c_void_p]),
+    "geo4d_align_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "geo4d_align_residual": (C.c_int, [C.POINTER(Align), C.c_void_p]),
+    "geo4d_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_int, C.c_void_p]),
     "geo4d_last_error": (C.c_char_p, []),
     "geo4d_abi_version": (C.c_int, []),
 }

@@ -1,0 +1,291 @@
+"""Multi-window global alignment — the stage the all-gathered clip feeds.
+
+``GroupAligner`` is the core of ``dust3r.cloud_opt.optimizer_group.LightPointCloudGroupOptimizer`` +
+``base_opt_group.global_alignment_loop`` (called by ``post_optimization``, scripts/evaluation/test_geo4d.py:30-51,509): the same
+parameters (per-image log-depth maps, camera poses as XYZW quaternion + signed-log1p translation, ``focal_break * log f`` focals —
+shared by default —, one sim(3) ``pw_poses`` row per window with the reference's scale normalisation), the same loss (the
+confidence-weighted L2-norm residual between re-projected depth points and the windows' aligned point maps, confidences clamped
+at 10, + the camera temporal-smoothing term) and the same optimiser (Adam, betas (0.9, 0.9), linear / cosine schedule).
+
+How an iteration runs here: ONE fused HIP kernel (csrc/align.hip) reads every window prediction once and produces the loss, the
+gradient of the depth maps and 3x3 / 3-vector gradient sums per image and per (window, frame); the chain rule from those sums to
+quaternions, log-translations, log-focal and log-scales is a few hundred flops per image and is taken by autograd over tiny device
+tensors (no host synchronisation); the depth maps get a fused HIP Adam step. The reference needs ~40 full-size elementwise kernels
+per iteration for the same numbers.
+
+Initialisation follows ``init_im_poses.align_group`` / ``init_from_pts3d_group`` (:82-181, :569-635): windows are chained by
+confidence-weighted similarity registration (``roma.rigid_points_registration`` = weighted Umeyama, restated here), ``pw_poses``
+come from registering every window to the chained cloud, depths are the z of the cloud in each camera. DEVIATION: the reference
+finds every camera by OpenCV RANSAC-PnP (cv2.solvePnPRansac — absent here and not reproducible); this module takes the per-window
+camera-to-world matrices that the Plücker ray maps already give (geo4d_amd/rays.py, N2) and a focal estimated from the first
+frame's point map. NOT built: the inverse-depth and trajectory terms the reference adds from iteration 150 on (its 5000-iteration
+LAD fit and evo's trajectory alignment).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+FOCAL_BREAK = 20.0
+
+
+def signed_expm1(x):
+    return torch.sign(x) * torch.expm1(torch.abs(x))
+
+
+def signed_log1p(x):
+    return torch.sign(x) * torch.log1p(torch.abs(x))
+
+
+def quat_to_rotmat(q):
+    """XYZW quaternion [..., 4] (normalised here) -> [..., 3, 3] (roma.RigidUnitQuat(...).normalize().to_homogeneous())."""
+    x, y, z, w = (q / q.norm(dim=-1, keepdim=True)).unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1).reshape(q.shape[:-1] + (3, 3))
+
+
+def rotmat_to_quat(R):
+    """[3, 3] -> XYZW unit quaternion (branch on the largest diagonal term; w >= 0 convention not enforced, like scipy)."""
+    R = R.double()
+    m00, m11, m22 = R[0, 0], R[1, 1], R[2, 2]
+    tr = m00 + m11 + m22
+    if tr > 0:
+        s = torch.sqrt(tr + 1.0) * 2
+        q = torch.stack([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    elif m00 > m11 and m00 > m22:
+        s = torch.sqrt(1.0 + m00 - m11 - m22) * 2
+        q = torch.stack([0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s, (R[2, 1] - R[1, 2]) / s])
+    elif m11 > m22:
+        s = torch.sqrt(1.0 + m11 - m00 - m22) * 2
+        q = torch.stack([(R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s, (R[0, 2] - R[2, 0]) / s])
+    else:
+        s = torch.sqrt(1.0 + m22 - m00 - m11) * 2
+        q = torch.stack([(R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s, (R[1, 0] - R[0, 1]) / s])
+    return (q / q.norm()).float()
+
+
+def rigid_points_registration(x, y, weights):
+    """(s, R, T) minimising sum w |s R x + T - y|^2 (init_im_poses.py:797-800 -> roma.rigid_points_registration(compute_scaling=True)):
+    weighted Umeyama, sums in fp64."""
+    x, y, w = x.reshape(-1, 3).double(), y.reshape(-1, 3).double(), weights.reshape(-1).double()
+    w = w / w.sum()
+    xm, ym = (w[:, None] * x).sum(0), (w[:, None] * y).sum(0)
+    xc, yc = x - xm, y - ym
+    U, S, Vt = torch.linalg.svd(((w[:, None] * yc).t() @ xc).cpu())
+    d = torch.sign(torch.det(U @ Vt))
+    D = torch.diag(torch.stack([torch.ones(()).double(), torch.ones(()).double(), d]))
+    R = (U @ D @ Vt).to(x.device)
+    s = (S * torch.diagonal(D)).sum().to(x.device) / (w * (xc * xc).sum(-1)).sum()
+    return s.float(), R.float(), (ym - s * (R @ xm)).float()
+
+
+def lr_at(t, schedule, lr_base, lr_min):
+    """commons.py:102-110."""
+    if schedule == "cosine":
+        return lr_min + (lr_base - lr_min) * (1 + np.cos(t * np.pi)) / 2
+    if schedule == "linear":
+        return lr_base + (lr_min - lr_base) * t
+    raise ValueError(f"bad lr schedule={schedule!r}")
+
+
+class GroupAligner:
+    def __init__(self, groups, pred, conf, shared_focal=True, temporal_smoothing_weight=0.0, translation_weight=0.1, base_scale=0.5,
+                 conf_clamp=10.0, chunk_pixels=1024):
+        """groups: list of G lists of S image indices; pred [G, S, H, W, 3], conf [G, S, H, W] fp32 on the HIP device."""
+        if not pred.is_cuda:
+            raise _lib.Geo4DNativeError("geo4d_amd.align.GroupAligner runs only on a HIP device (there is no CPU fallback)")
+        self.lib = _lib.load()
+        G, S, H, W, _ = pred.shape
+        self.groups, self.G, self.S, self.H, self.W = [list(g) for g in groups], G, S, H, W
+        self.n = 1 + max(max(g) for g in self.groups)
+        self.dev = pred.device
+        self.pred = pred.reshape(G * S, H * W, 3).float().contiguous()
+        self.conf = conf.reshape(G * S, H * W).float().contiguous()
+        self.shared_focal, self.tsw, self.tw, self.base_scale, self.conf_clamp = shared_focal, temporal_smoothing_weight, translation_weight, base_scale, conf_clamp
+        self.norm_pw_scale = True
+        e_all = [i for g in self.groups for i in g]
+        slots = [[s for s, i in enumerate(e_all) if i == img] for img in range(self.n)]
+        if any(len(s) == 0 for s in slots):
+            raise ValueError("every image must belong to at least one window")
+        self.max_slots = max(len(s) for s in slots)
+        ptr = np.concatenate([[0], np.cumsum([len(s) for s in slots])]).astype(np.int32)
+        self.slot_ptr = torch.from_numpy(ptr).to(self.dev)
+        self.slot_idx = torch.tensor([s for lst in slots for s in lst], dtype=torch.int32, device=self.dev)
+        self.slot_order = torch.tensor([s for lst in slots for s in lst], dtype=torch.long, device=self.dev)   # CSR position -> slot
+        self.slot_group = torch.tensor([s // S for s in range(G * S)], dtype=torch.long, device=self.dev)
+        self.chunk = chunk_pixels
+        f0 = FOCAL_BREAK * math.log(max(H, W))
+        z = lambda *s: torch.zeros(s, device=self.dev)
+        self.P = {"im_depthmaps": z(self.n, H * W), "im_poses": torch.cat([z(self.n, 3), torch.ones(self.n, 1, device=self.dev), z(self.n, 3)], 1),
+                  "im_focals": torch.full((1 if shared_focal else self.n, 1), f0, device=self.dev),
+                  "pw_poses": torch.cat([z(G, 3), torch.ones(G, 1, device=self.dev), z(G, 4)], 1)}
+        need = self.lib.geo4d_align_workspace(self.n, G * S, H, W, self.chunk)
+        self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        self._img_sums, self._slot_sums = z(self.n, 14), z(G * S, 12)
+        self._grad_ld = z(self.n, H * W)
+        self._pp = torch.tensor([W / 2, H / 2], device=self.dev)
+
+    # ---- parameter -> geometry (tiny device tensors, differentiable) -----------------------------------------------------------
+    def get_focals(self):
+        lf = self.P["im_focals"]
+        return (lf.expand(self.n, 1) / FOCAL_BREAK).exp()
+
+    def get_im_poses(self):
+        p = self.P["im_poses"]
+        return quat_to_rotmat(p[:, :4]), signed_expm1(p[:, 4:7])
+
+    def get_pw_scale(self):
+        ls = self.P["pw_poses"][:, -1]
+        scale = ls.exp()
+        if self.norm_pw_scale:
+            scale = scale * (math.log(self.base_scale) - ls.mean()).exp()
+        return scale
+
+    def get_pw_poses(self):
+        p = self.P["pw_poses"]
+        s = self.get_pw_scale().view(-1, 1, 1)
+        return quat_to_rotmat(p[:, :4]) * s, signed_expm1(p[:, 4:7]) * s.view(-1, 1)      # scales rotation AND translation
+
+    def get_depthmaps(self):
+        return self.P["im_depthmaps"].exp().reshape(self.n, self.H, self.W)
+
+    def get_im_poses_matrix(self):
+        R, t = self.get_im_poses()
+        M = torch.eye(4, device=self.dev).repeat(self.n, 1, 1)
+        M[:, :3, :3], M[:, :3, 3] = R, t
+        return M
+
+    def get_pts3d(self):
+        """World points [n, H, W, 3] from depth / pose / focal (optimizer_group.py:407-417)."""
+        R, t = self.get_im_poses()
+        f = self.get_focals().reshape(self.n, 1, 1)
+        ys, xs = torch.meshgrid(torch.arange(self.H, device=self.dev), torch.arange(self.W, device=self.dev), indexing="ij")
+        grid = torch.stack([xs, ys], -1).reshape(1, -1, 2).float()
+        d = self.P["im_depthmaps"].exp().unsqueeze(-1)
+        cam = torch.cat([d * (grid - self._pp) / f, d], -1)
+        return (cam @ R.transpose(1, 2) + t[:, None]).reshape(self.n, self.H, self.W, 3)
+
+    # ---- one loss / gradient evaluation ---------------------------------------------------------------------------------------
+    def loss_and_grads(self):
+        """Returns (loss 0-dim device tensor, dict of gradients shaped like self.P)."""
+        small = {k: self.P[k].detach().clone().requires_grad_(True) for k in ("im_poses", "im_focals", "pw_poses")}
+        saved, self.P = self.P, dict(self.P, **small)
+        try:
+            R, t = self.get_im_poses()
+            f = self.get_focals()
+            sR, st = self.get_pw_poses()
+        finally:
+            self.P = saved
+        cams = torch.cat([R.reshape(self.n, 9), t, f, self._pp.expand(self.n, 2), torch.zeros(self.n, 1, device=self.dev)], 1).detach().contiguous()
+        trf = torch.cat([sR.reshape(self.G, 9), st], 1).detach()[self.slot_group].contiguous()
+        a = _lib.Align()
+        a.pred, a.conf, a.logdepth, a.cams, a.slot_trf = self.pred.data_ptr(), self.conf.data_ptr(), self.P["im_depthmaps"].data_ptr(), cams.data_ptr(), trf.data_ptr()
+        a.slot_ptr, a.slot_idx = self.slot_ptr.data_ptr(), self.slot_idx.data_ptr()
+        a.grad_logdepth, a.img_sums, a.slot_sums = self._grad_ld.data_ptr(), self._img_sums.data_ptr(), self._slot_sums.data_ptr()
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        a.n_imgs, a.n_slots, a.H, a.W, a.chunk_pixels, a.max_slots_per_image = self.n, self.G * self.S, self.H, self.W, self.chunk, self.max_slots
+        a.conf_clamp, a.inv_area = self.conf_clamp, 1.0 / float(self.G * self.S * self.H * self.W)
+        _lib.check(self.lib.geo4d_align_residual(C.byref(a), ops._stream()), "geo4d_align_residual")
+        I = self._img_sums
+        # slot sums come back in CSR (image-major) order: put them in slot order, then add the S frames of each window
+        Ssum = torch.zeros_like(self._slot_sums).index_copy_(0, self.slot_order, self._slot_sums).reshape(self.G, self.S, 12).sum(1)
+        loss = I[:, 13].sum()
+        # chain rule through the tiny parameter -> matrix maps: d loss = <dL/dR, dR> + <dL/dt, dt> + dL/df df + <dL/dsR, dsR> + <dL/dst, dst>
+        surrogate = (I[:, :9].reshape(self.n, 3, 3) * R).sum() + (I[:, 9:12] * t).sum() + (I[:, 12:13] * f).sum() + \
+            (Ssum[:, :9].reshape(self.G, 3, 3) * sR).sum() + (Ssum[:, 9:12] * st).sum()
+        if self.tsw > 0 and self.n > 1:
+            M = torch.eye(4, device=self.dev).repeat(self.n, 1, 1)
+            M = torch.cat([torch.cat([R, t[:, :, None]], 2), M[:, 3:]], 1)
+            rel = torch.linalg.inv(M[:-1]) @ M[1:]
+            smooth = (torch.norm(rel[:, :3, :3] - torch.eye(3, device=self.dev), dim=(1, 2)) + torch.norm(rel[:, :3, 3], dim=1) * self.tw).sum()
+            surrogate = surrogate + self.tsw * smooth
+            loss = loss + self.tsw * smooth.detach()
+        surrogate.backward()
+        grads = {k: v.grad for k, v in small.items()}
+        grads["im_depthmaps"] = self._grad_ld
+        return loss, grads
+
+    # ---- optimisation loop (base_opt_group.py:553-626) --------------------------------------------------------------------------
+    def compute_global_alignment(self, niter=300, lr=0.01, lr_min=1e-3, schedule="cosine", history=False):
+        keys = ("im_poses", "im_focals", "pw_poses")
+        small = [self.P[k].requires_grad_(True) for k in keys]
+        opt = torch.optim.Adam(small, lr=lr, betas=(0.9, 0.9))
+        m, v = torch.zeros_like(self.P["im_depthmaps"]), torch.zeros_like(self.P["im_depthmaps"])
+        hist, loss = [], None
+        for it in range(niter):
+            cur = float(lr_at(it / niter, schedule, lr, lr_min))
+            for g in opt.param_groups:
+                g["lr"] = cur
+            loss, grads = self.loss_and_grads()
+            for k, p in zip(keys, small):
+                p.grad = grads[k]
+            opt.step()
+            d = self.P["im_depthmaps"]
+            _lib.check(self.lib.geo4d_adam_step(d.data_ptr(), grads["im_depthmaps"].data_ptr(), m.data_ptr(), v.data_ptr(), d.numel(), cur, 0.9, 0.9,
+                                                1e-8, it + 1, ops._stream()), "geo4d_adam_step")
+            if history:
+                hist.append(loss)
+        for p in small:
+            p.requires_grad_(False)
+        return (float(loss) if loss is not None else float("inf")), ([float(h) for h in hist] if history else None)
+
+    # ---- initialisation (init_im_poses.py:82-181, 569-635) ----------------------------------------------------------------------
+    @torch.no_grad()
+    def init_from_group(self, traj, focal=None):
+        """traj [G, S, 4, 4]: camera-to-world of every frame in its window's own frame (the Plücker cameras of N2);
+        focal: pixels (None: estimated from window 0's first point map)."""
+        G, S, H, W = self.G, self.S, self.H, self.W
+        pred = self.pred.reshape(G, S, H * W, 3)
+        conf = self.conf.reshape(G, S, H * W)
+        pts3d, conf_list, im_poses = [None] * self.n, [None] * self.n, [None] * self.n
+        done = set()
+        for k, i in enumerate(self.groups[0]):
+            pts3d[i], conf_list[i], im_poses[i] = pred[0, k].clone(), conf[0, k].clone(), traj[0, k].clone().float()
+            done.add(i)
+        for g in range(1, G):
+            grp = self.groups[g]
+            seen = [k for k, i in enumerate(grp) if i in done]
+            assert seen and grp[0] in done, "the first image of every window must belong to an earlier window"
+            s, R, T = rigid_points_registration(pred[g, seen], torch.stack([pts3d[grp[k]] for k in seen]),
+                                                torch.stack([conf[g, k] * conf_list[grp[k]] for k in seen]))
+            for k, i in enumerate(grp):       # later windows overwrite earlier estimates, as the reference does
+                pts3d[i], conf_list[i] = s * (pred[g, k] @ R.t()) + T, conf[g, k].clone()
+                done.add(i)
+                M = torch.eye(4, device=self.dev)
+                M[:3, :3] = R @ traj[g, k, :3, :3].float()
+                M[:3, 3] = s * (R @ traj[g, k, :3, 3].float()) + T
+                im_poses[i] = M
+        # pairwise poses: register every window onto the chained cloud
+        for g, grp in enumerate(self.groups):
+            s, R, T = rigid_points_registration(pred[g], torch.stack([pts3d[i] for i in grp]), torch.stack([conf[g, k] * conf_list[i] for k, i in enumerate(grp)]))
+            self.P["pw_poses"][g, :4] = rotmat_to_quat(R).to(self.dev)
+            self.P["pw_poses"][g, 4:7] = signed_log1p(T / s)
+            self.P["pw_poses"][g, 7] = torch.log(s)
+        sf = float((math.log(self.base_scale) - self.P["pw_poses"][:, -1].mean()).exp()) if self.norm_pw_scale else 1.0
+        if focal is None:
+            p0, ys, xs = pred[0, 0], *torch.meshgrid(torch.arange(H, device=self.dev), torch.arange(W, device=self.dev), indexing="ij")
+            u, v = (xs.reshape(-1).float() - W / 2), (ys.reshape(-1).float() - H / 2)
+            ok = (p0[:, 2] > 1e-6) & (conf[0, 0] > 0.5)
+            fx = (u * p0[:, 2] / p0[:, 0])[ok & (u.abs() > W / 8)]
+            fy = (v * p0[:, 2] / p0[:, 1])[ok & (v.abs() > H / 8)]
+            cand = torch.cat([fx[torch.isfinite(fx)], fy[torch.isfinite(fy)]])
+            focal = float(cand.median()) if cand.numel() else float(max(H, W))
+        self.P["im_focals"][:] = FOCAL_BREAK * math.log(focal)
+        sky = 0.0
+        for i in range(self.n):
+            M = im_poses[i].clone()
+            M[:3, 3] *= sf
+            Rw, tw = M[:3, :3], M[:3, 3]
+            depth = ((pts3d[i] * sf - tw) @ Rw)[:, 2]                      # z of R^T (X - t)
+            skym = conf_list[i] < 1e-4
+            if i == 0:
+                sky = depth.max()
+            depth = torch.where(skym, torch.as_tensor(sky, device=self.dev), depth)
+            self.P["im_depthmaps"][i] = depth.clamp_min(1e-6).log().nan_to_num(neginf=0)
+            self.P["im_poses"][i, :4] = rotmat_to_quat(Rw).to(self.dev)
+            self.P["im_poses"][i, 4:7] = signed_log1p(tw)
+        return self

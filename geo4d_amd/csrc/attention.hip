@@ -462,7 +462,9 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     // per SIMD (128-VGPR budget), 3 = 256 rows / workgroup, two query blocks per wave (self-attention only)
     int variant = p.variant;
     if (variant < 0 || variant > 3) { geo4d_set_error("attention: unknown variant"); return GEO4D_EINVAL; }
-    if (variant == 0) variant = 1;
+    // default (measured, profiles/r02_attention_variants.md): two query blocks per wave for 16-bit self-attention (bf16 N = 2560:
+    // 245 -> 199 us), one for the 4-byte storage modes (their two-block build spills: bf16x3 523 -> 563 us)
+    if (variant == 0) variant = (p.nseg == 1 && (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16)) ? 3 : 1;
     if (p.nseg == 2 || p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3) {
         if (variant == 3 && p.nseg == 2) variant = 1;     // dual-KV cross attention: one query block per wave
         if (variant == 2 && (p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3)) variant = 1;   // 4-byte storage needs > 128 VGPRs

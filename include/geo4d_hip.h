@@ -170,6 +170,30 @@ size_t geo4d_plucker_cameras_workspace(int T, int H, int W);
 int geo4d_plucker_cameras(const float* ray, const float* moment, long channel_stride, long frame_stride, int T, int H, int W,
                           void* workspace, size_t workspace_bytes, float* P_c2w, void* stream);
 
+/* Multi-window global alignment, one iteration's residual + gradients. replaces the autograd forward /
+ * backward of LightPointCloudGroupOptimizer.forward's point-map term (dust3r/cloud_opt/optimizer_group.py:440-455 with
+ * depth_to_pts3d :407-417 and l1_dist commons.py:86-87). A "slot" is one (window, frame) prediction; image i owns the slots
+ * slot_idx[slot_ptr[i] .. slot_ptr[i+1]).  loss = inv_area * sum min(conf, conf_clamp) * | X_i - (sR_g P + st_g) |.
+ *   pred [n_slots][H*W][3], conf [n_slots][H*W], logdepth / grad_logdepth [n_imgs][H*W]          (fp32, device)
+ *   cams [n_imgs][16] = R (9, row-major) | t (3) | focal | ppx | ppy | 0      slot_trf [n_slots][12] = sR (9) | st (3)
+ *   img_sums [n_imgs][14] = dL/dR (9) | dL/dt (3) | dL/dfocal | loss share     slot_sums [n_slots][12] = dL/d(sR) (9) | dL/d(st) (3)
+ * workspace: geo4d_align_workspace bytes. Deterministic (fixed-order reductions). */
+typedef struct geo4d_align_t {
+    const float* pred; const float* conf; const float* logdepth; const float* cams; const float* slot_trf;
+    const int* slot_ptr; const int* slot_idx;
+    float* grad_logdepth; float* img_sums; float* slot_sums;
+    void* workspace; size_t workspace_bytes;
+    float* img_part; float* slot_part;   /* set by the library (views of workspace) */
+    int n_imgs, n_slots, H, W, chunk_pixels, max_slots_per_image;
+    float conf_clamp, inv_area;
+} geo4d_align_t;
+size_t geo4d_align_workspace(int n_imgs, int n_slots, int H, int W, int chunk_pixels);
+int geo4d_align_residual(const geo4d_align_t* p, void* stream);
+/* One torch.optim.Adam step on a flat fp32 tensor (no weight decay / amsgrad); `step` counts from 1.
+ * replaces optimizer.step() of global_alignment_iter (dust3r/cloud_opt/base_opt_group.py:596-626) for the depth maps. */
+int geo4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                    float eps, int step, void* stream);
+
 const char* geo4d_last_error(void);
 int geo4d_abi_version(void);
 
