@@ -150,7 +150,7 @@ def test_tuning_table_uses_only_known_tile_hints():
     for key, (tile, split) in table.items():
         assert tile in documented, (key, tile)
         assert split in (0, 1, 2, 4, 8, 16), (key, split)
-        assert re.match(r"^\d/\d\|\d+x\d+x\d+\|c\d+\|t\d{3}s\du\d\|a\dr\dn\d\|b\d+$", key), key
+        assert re.match(r"^\d/\d\|\d+x\d+x\d+\|c\d+\|t\d{3}s\du\d\|a\dr\dn\d\|b\d+(\|x[01][01])?$", key), key   # |xAW: bf16x3 pre-split operand flags
     assert all(t in documented for t, _ in ops._CANDIDATES)
 
 
