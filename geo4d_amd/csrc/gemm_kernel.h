@@ -184,7 +184,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
 #pragma unroll
             for (int j = 0; j < 2; ++j) foffx[s2][j] = li * PITCH + (((4 * s2 + 2 * g + j) ^ ((li >> 1) & 7)) << 4);
     }
-    const bool a_split = p.a_split != 0, w_split = p.w_split != 0;
+    // debug_ablate = 1 (tools/gemm_bench.py --ablate): treat raw f32 operands as if pre-split, i.e. skip the in-register split -
+    // WRONG numbers, used only to measure what the split's VALU work costs
+    const bool a_split = p.a_split != 0 || p.debug_ablate == 1, w_split = p.w_split != 0 || p.debug_ablate == 1;
     auto compute_slab = [&](int buf) {
         const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
         const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;

@@ -154,7 +154,7 @@ class LatentDiffusion(nn.Module):
                 raise NotImplementedError(f"{name}: no geo4d_amd front-end configured ({cfg_attr} = {cfg!r}); pass precomputed `cond` tensors "
                                           "or point the yaml section at geo4d_amd.encoders.*")
             cfg = {"target": cfg["target"], "params": dict(cfg.get("params") or {}, compute_dtype=getattr(unet, "compute_dtype", None))}
-            self.add_module(name, instantiate_from_config(cfg).to(self.device))
+            self._modules[name] = instantiate_from_config(cfg).to(self.device)     # (add_module would probe hasattr -> __getattr__ -> here)
         return self
 
     def get_learned_conditioning(self, c):

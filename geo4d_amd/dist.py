@@ -23,12 +23,15 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = backend or os.environ.get("GEO4D_DIST_BACKEND") or None
+    if os.environ.get("GEO4D_SINGLE_DEVICE") == "1":      # test rig: several ranks share GPU 0 (gloo only; RCCL refuses duplicate devices)
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
@@ -46,9 +49,19 @@ def window_owner_table(num_windows, world):
     return counts, max(counts) if counts else 0
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 def _all_gather(out, inp, group=None, async_op=False):
-    if hasattr(dist, "all_gather_into_tensor") and inp.is_cuda:
+    if inp.is_cuda and dist.get_backend(group) == "nccl":
         return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)    # one RCCL all-gather over xGMI
+    if inp.is_cuda:        # gloo with device tensors (single-GPU test rig of the N > 1 path): stage through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather(list(host.chunk(dist.get_world_size(group), 0)), inp.cpu(), group=group)
+        out.copy_(host)
+        return _Done() if async_op else None
     return dist.all_gather(list(out.chunk(dist.get_world_size(group), 0)), inp, group=group, async_op=async_op)   # gloo (CPU tests)
 
 

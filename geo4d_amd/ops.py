@@ -75,6 +75,7 @@ _TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning
 _TUNE = None
 _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1), (17, 2), (16, 2), (17, 8), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
+DEBUG_ABLATE = 0       # tools/gemm_bench.py --ablate only
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
 
 
@@ -163,7 +164,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.rowbias_div, p.bias_per_row, p.act = rowbias_div, int(bias_per_row), act
     p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = code, dt_code(out.dtype), int(out_nchw), tile_hint
     p.alpha, p.split_k = alpha, split_k
-    p.debug_ablate = 0
+    p.debug_ablate = DEBUG_ABLATE
     p.a_split, p.w_split = int(a_split), int(w_split)
     ws, zeros = workspace(a.device)
     p.workspace, p.workspace_bytes, p.zeros = ws.data_ptr(), ws.numel(), zeros.data_ptr()

@@ -62,7 +62,7 @@ typedef struct geo4d_conv_gemm_t {
                             (N = 320 layers: one tile per CU at M = 40960), 17 = 160x160 with 5 waves; no
                             GEGLU on 16 / 17. Others: -EINVAL */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
-    int debug_ablate;    /* reserved (was a profiling knob): must be 0                   */
+    int debug_ablate;    /* 0 in production. 1 (bf16x3 profiling only): skip the in-register hi/lo split -> WRONG results */
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */

@@ -433,3 +433,61 @@ def test_rccl_path_executes_on_one_gpu(dev):
         assert t.tolist() == [1.0, 1.0, 1.0]
     finally:
         dist.destroy_process_group()
+
+
+def test_captured_step_is_reused_across_windows_and_survives_model_changes(dev):
+    """The sampler owns static copies of the conditioning: a second sample() with NEW conditioning values of the same shapes
+    replays the captured step (context K/V refreshed in place) and must equal a fresh sampler bit for bit; after the weights
+    change (load_state_dict -> re-pack) the capture is dropped instead of replaying over freed tensors."""
+    from geo4d_amd.ddim import DDIMSampler
+    m, u, _ = _diffusion(dev, "bf16")
+    gen = torch.Generator().manual_seed(41)
+    B, T, h, w = 1, 4, 8, 8
+    cd = u["unet_config"]["context_dim"]
+    mk = lambda: {"c_crossattn": [torch.randn((B, 77 + 16 * T, cd), generator=gen).to(dev)], "c_concat": [torch.randn((B, 4, T, h, w), generator=gen).to(dev)]}
+    cond_a, cond_b = mk(), mk()
+    x_T = torch.randn((B, 16, T, h, w), generator=gen).to(dev)
+    kw = dict(S=4, batch_size=B, shape=[16, T, h, w], verbose=False, eta=0.0, fs=torch.tensor([24], device=dev), x_T=x_T,
+              timestep_spacing="uniform_trailing", unconditional_conditioning_img_nonetext=None)
+    s = DDIMSampler(m)
+    a1, _ = s.sample(conditioning=cond_a, **kw)
+    g_first = s._static["g"]
+    b1, _ = s.sample(conditioning=cond_b, **kw)                       # same shapes, new values: replay
+    assert s._static["g"] is g_first, "the captured step should have been reused"
+    b_ref, _ = DDIMSampler(m).sample(conditioning=cond_b, **kw)
+    a_ref, _ = DDIMSampler(m, use_graph=False).sample(conditioning=cond_a, **kw)
+    assert torch.equal(b1, b_ref) and torch.equal(a1, a_ref) and not torch.equal(a1, b1)
+    sd = {k: v * 1.01 for k, v in m.model.diffusion_model.state_dict().items()}
+    m.model.diffusion_model.load_state_dict(sd)                       # re-pack: the old capture's weight pointers are gone
+    c1, _ = s.sample(conditioning=cond_b, **kw)
+    assert s._static["g"] is not g_first, "a capture must not outlive the packed weights it baked in"
+    c_ref, _ = DDIMSampler(m, use_graph=False).sample(conditioning=cond_b, **kw)
+    assert torch.equal(c1, c_ref) and not torch.equal(c1, b1)
+
+
+def test_guided_synthesis_encodes_the_latent_for_every_branch(dev):
+    """CFG through image_guided_synthesis: the caller supplies only the cross-attention contexts; the video latent
+    computed from `videos` must reach the unconditional (and image-only) branches too (test_geo4d.py:184-195) — equal to a
+    direct sampler call with hand-built dicts."""
+    from geo4d_amd.ddim_multiplecond import DDIMSampler as Multi
+    from geo4d_amd.pipeline import decode_modalities, get_latent_z, image_guided_synthesis
+    m, u, _ = _diffusion(dev, "f32")
+    gen = torch.Generator().manual_seed(43)
+    B, T = 1, 4
+    cd = u["unet_config"]["context_dim"]
+    videos = (torch.rand((B, 3, T, 64, 64), generator=gen) * 2 - 1).to(dev)
+    ctx = [torch.randn((B, 77 + 16 * T, cd), generator=gen).to(dev) for _ in range(3)]
+    x_T = torch.randn((B, 16, T, 8, 8), generator=gen).to(dev)
+    torch.manual_seed(9)
+    out = image_guided_synthesis(m, [""], videos, [B, 16, T, 8, 8], n_samples=1, ddim_steps=3, ddim_eta=0.0, unconditional_guidance_scale=7.5,
+                                 cfg_img=2.0, fs=24, multiple_cond_cfg=True, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                 cond={"c_crossattn": [ctx[0]]}, x_T=x_T, unconditional_conditioning={"c_crossattn": [ctx[1]]},
+                                 unconditional_conditioning_img_nonetext={"c_crossattn": [ctx[2]]})
+    torch.manual_seed(9)
+    z = get_latent_z(m, videos)
+    mk = lambda c: {"c_crossattn": [c], "c_concat": [z]}
+    lat, _ = Multi(m).sample(S=3, conditioning=mk(ctx[0]), batch_size=B, shape=[16, T, 8, 8], verbose=False, eta=0.0,
+                             unconditional_guidance_scale=7.5, unconditional_conditioning=mk(ctx[1]), cfg_img=2.0,
+                             unconditional_conditioning_img_nonetext=mk(ctx[2]), fs=torch.tensor([24], device=dev), x_T=x_T,
+                             timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    assert torch.isfinite(out).all() and torch.equal(out[:, 0], decode_modalities(m, lat, None))

@@ -57,8 +57,13 @@ def main():
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--vendor", action="store_true", help="also time the vendor library on the same shape (hipBLASLt via F.linear, MIOpen via F.conv2d channels_last): a calibration point, never used by the product path")
     ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
+    ap.add_argument("--ablate", type=int, default=0, help="bf16x3 only: 1 = skip the in-register operand split (wrong numbers; measures its cost)")
     args = ap.parse_args()
-    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    ops.DEBUG_ABLATE = args.ablate
+    x3 = args.dtype == "bf16x3"
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "bf16x3": torch.float32}[args.dtype]
+    from geo4d_amd import pack
+    wcast = (lambda w: pack.split_bf16(w)) if x3 else (lambda w: w.to(dt))
     dev = torch.device("cuda:0")
     tot_ms, tot_tf = 0.0, 0.0
     print(f"{'shape':34s} {'M':>8s} {'N':>6s} {'K':>6s} {'us':>9s} {'TF/s':>8s}  x count -> ms/forward")
@@ -69,7 +74,7 @@ def main():
             F_, H, W = geo
             M, K = F_ * H * W, 9 * Cin
             x = torch.randn((M, Cin), device=dev).to(dt)
-            w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
+            w = wcast(torch.randn((N, K), device=dev) / K ** 0.5)
             b = torch.randn((N,), device=dev)
             r = torch.randn((M, N), device=dev).to(dt)
             fn = lambda tile=args.tile, split=args.split: ops.conv2d(x, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=r, tile_hint=tile, split_k=split)
@@ -77,13 +82,13 @@ def main():
             T, HW = geo
             M, K = T * HW, 3 * Cin
             x = torch.randn((M, Cin), device=dev).to(dt)
-            w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
+            w = wcast(torch.randn((N, K), device=dev) / K ** 0.5)
             b = torch.randn((N,), device=dev)
-            fn = lambda tile=args.tile, split=args.split: ops.conv_gemm(x, w, torch.empty((M, N), device=dev, dtype=dt), M=M, N=N, K=K, Cin=Cin, lda=Cin, ldw=K, ldo=N, T=T, Hin=HW, Win=1, Hout=HW, Wout=1, KT=3, pt=1, bias=b, residual=x, ldr=Cin, tile_hint=tile, split_k=split)
+            fn = lambda tile=args.tile, split=args.split: ops.conv_gemm(x, w, torch.empty((M, N), device=dev, dtype=dt), M=M, N=N, K=K, Cin=Cin, lda=Cin, ldw=w.stride(0), ldo=N, T=T, Hin=HW, Win=1, Hout=HW, Wout=1, KT=3, pt=1, bias=b, residual=x, ldr=Cin, tile_hint=tile, split_k=split)
         else:
             M, K = geo, Cin
             x = torch.randn((M, K), device=dev).to(dt)
-            w = (torch.randn((N, K), device=dev) / K ** 0.5).to(dt)
+            w = wcast(torch.randn((N, K), device=dev) / K ** 0.5)
             b = torch.randn((N,), device=dev)
             act = 2 if kind == "geglu" else 0
             fn = lambda tile=args.tile, split=args.split: ops.linear(x, w, b, act=act, tile_hint=tile, split_k=split)

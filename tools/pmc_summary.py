@@ -28,7 +28,7 @@ def main():
     out_md, out_json, files = sys.argv[1], sys.argv[2], sys.argv[3:]
     per = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum
     calls = defaultdict(set)
-    for f in files:
+    for fi, f in enumerate(files):
         rows = list(csv.DictReader(open(f, newline="")))
         marks = sorted({int(r["Dispatch_Id"]) for r in rows if "timestep_embedding" in r["Kernel_Name"]})
         assert len(marks) >= 2, f"{f}: no U-Net forward found"
@@ -39,7 +39,8 @@ def main():
                 continue
             k = short(r["Kernel_Name"])
             per[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            calls[k].add(d)
+            if fi == 0:                  # dispatch ids differ between passes (first-use tuning): count launches in ONE pass
+                calls[k].add(d)
     tot = defaultdict(float)
     for k in per:
         for c, v in per[k].items():
