@@ -95,6 +95,14 @@ def test_init_from_group_and_convergence_at_window_size(dev):
     # the focal gradient is ONE scalar summed over 70 k signed per-pixel terms in fp32 (here chunk by chunk, in torch as a tree)
     assert abs(float(loss0) - float(ref)) < 1e-4 * float(ref) and max(errs.values()) < 3e-3 and errs["im_depthmaps"] < 1e-3, errs
     assert float(loss0) < 0.05 and abs(float(a.get_focals()[0]) - f) < 0.1 * f          # the chained initialisation is already close
-    final, hist = a.compute_global_alignment(niter=60, lr=0.01, schedule="linear", history=True)
-    print(f"[align 28 frames] 60 iterations: {hist[0]:.5f} -> {hist[-1]:.5f}")
-    assert hist[-1] < 0.7 * hist[0] and torch.isfinite(a.get_depthmaps()).all()
+    final, hist = a.compute_global_alignment(niter=30, lr=0.003, schedule="linear", history=True)
+    print(f"[align 28 frames] from the chained init (already at the noise floor): {hist[0]:.5f} -> {hist[-1]:.5f}")
+    assert hist[-1] < 1.05 * hist[0] and torch.isfinite(a.get_depthmaps()).all()
+    # knock the solution off (window sim(3)s, camera translations, depth scale) and let the loop pull it back
+    gen2 = torch.Generator().manual_seed(5)
+    a.P["pw_poses"][:, 4:8] += 0.05 * torch.randn((len(groups), 4), generator=gen2).to(dev)
+    a.P["im_poses"][:, 4:7] += 0.05 * torch.randn((n, 3), generator=gen2).to(dev)
+    a.P["im_depthmaps"] += 0.1
+    final, hist = a.compute_global_alignment(niter=150, lr=0.01, schedule="linear", history=True)
+    print(f"[align 28 frames] after a perturbation, 150 iterations: {hist[0]:.5f} -> {hist[-1]:.5f}")
+    assert hist[0] > 3 * float(loss0) and hist[-1] < 0.35 * hist[0]
