@@ -111,6 +111,8 @@ SIGNATURES = {
     "geo4d_align_residual": (C.c_int, [C.POINTER(Align), C.c_void_p]),
     "geo4d_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int, C.c_void_p]),
+    "geo4d_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                      C.c_void_p]),
     "geo4d_last_error": (C.c_char_p, []),
     "geo4d_abi_version": (C.c_int, []),
 }

@@ -198,10 +198,11 @@ class GroupAligner:
         surrogate = (I[:, :9].reshape(self.n, 3, 3) * R).sum() + (I[:, 9:12] * t).sum() + (I[:, 12:13] * f).sum() + \
             (Ssum[:, :9].reshape(self.G, 3, 3) * sR).sum() + (Ssum[:, 9:12] * st).sum()
         if self.tsw > 0 and self.n > 1:
-            M = torch.eye(4, device=self.dev).repeat(self.n, 1, 1)
-            M = torch.cat([torch.cat([R, t[:, :, None]], 2), M[:, 3:]], 1)
-            rel = torch.linalg.inv(M[:-1]) @ M[1:]
-            smooth = (torch.norm(rel[:, :3, :3] - torch.eye(3, device=self.dev), dim=(1, 2)) + torch.norm(rel[:, :3, 3], dim=1) * self.tw).sum()
+            # relative_pose_loss (optimizer_group.py:529-541): inverse(RT1) @ RT2 with RT rigid, so inverse = [R^T | -R^T t]
+            # (no batched LU on the device: keeps the iteration capturable)
+            Rt = R[:-1].transpose(1, 2)
+            rel_R, rel_t = Rt @ R[1:], (Rt @ (t[1:] - t[:-1])[:, :, None])[:, :, 0]
+            smooth = (torch.norm(rel_R - torch.eye(3, device=self.dev), dim=(1, 2)) + torch.norm(rel_t, dim=1) * self.tw).sum()
             surrogate = surrogate + self.tsw * smooth
             loss = loss + self.tsw * smooth.detach()
         surrogate.backward()
@@ -210,28 +211,58 @@ class GroupAligner:
         return loss, grads
 
     # ---- optimisation loop (base_opt_group.py:553-626) --------------------------------------------------------------------------
-    def compute_global_alignment(self, niter=300, lr=0.01, lr_min=1e-3, schedule="cosine", history=False):
+    def compute_global_alignment(self, niter=300, lr=0.01, lr_min=1e-3, schedule="cosine", history=False, use_graph=True):
+        """Adam (betas 0.9 / 0.9, eps 1e-8, bias-corrected: torch.optim.Adam's arithmetic) under the reference's schedule. One
+        iteration = fused residual kernel + tiny chain rule + fused Adam on the depth maps + Adam on the small parameters, with
+        lr and the bias corrections read from device tables indexed by a device counter — so ONE captured hipGraph is replayed
+        `niter` times with no host work in between (`use_graph`; the eager loop runs the same kernels)."""
         keys = ("im_poses", "im_focals", "pw_poses")
-        small = [self.P[k].requires_grad_(True) for k in keys]
-        opt = torch.optim.Adam(small, lr=lr, betas=(0.9, 0.9))
-        m, v = torch.zeros_like(self.P["im_depthmaps"]), torch.zeros_like(self.P["im_depthmaps"])
-        hist, loss = [], None
-        for it in range(niter):
-            cur = float(lr_at(it / niter, schedule, lr, lr_min))
-            for g in opt.param_groups:
-                g["lr"] = cur
+        b1 = b2 = 0.9
+        eps = 1e-8
+        steps = torch.arange(1, niter + 1, dtype=torch.float64)
+        table = torch.stack([torch.tensor([lr_at(it / niter, schedule, lr, lr_min) for it in range(niter)], dtype=torch.float64),
+                             1 - b1 ** steps, (1 - b2 ** steps).sqrt()], 1).float().to(self.dev)            # [niter, 3]
+        idx = torch.zeros((1,), dtype=torch.long, device=self.dev)
+        hyper = torch.zeros(3, device=self.dev)
+        mom = {k: (torch.zeros_like(self.P[k]), torch.zeros_like(self.P[k])) for k in ("im_depthmaps",) + keys}
+        losses = torch.zeros(niter, device=self.dev)
+
+        def iteration():
+            hyper.copy_(table.index_select(0, idx)[0])
             loss, grads = self.loss_and_grads()
-            for k, p in zip(keys, small):
-                p.grad = grads[k]
-            opt.step()
-            d = self.P["im_depthmaps"]
-            _lib.check(self.lib.geo4d_adam_step(d.data_ptr(), grads["im_depthmaps"].data_ptr(), m.data_ptr(), v.data_ptr(), d.numel(), cur, 0.9, 0.9,
-                                                1e-8, it + 1, ops._stream()), "geo4d_adam_step")
-            if history:
-                hist.append(loss)
-        for p in small:
-            p.requires_grad_(False)
-        return (float(loss) if loss is not None else float("inf")), ([float(h) for h in hist] if history else None)
+            losses.index_copy_(0, idx, loss.reshape(1))
+            d, (m, v) = self.P["im_depthmaps"], mom["im_depthmaps"]
+            _lib.check(self.lib.geo4d_adam_step_dev(d.data_ptr(), grads["im_depthmaps"].data_ptr(), m.data_ptr(), v.data_ptr(), d.numel(),
+                                                    hyper.data_ptr(), b1, b2, eps, ops._stream()), "geo4d_adam_step_dev")
+            for k in keys:                              # a few dozen numbers each: plain tensor ops, same formula
+                g, (m, v) = grads[k], mom[k]
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                self.P[k].sub_((hyper[0] / hyper[1]) * m / (v.sqrt() / hyper[2] + eps))
+            idx.add_(1)
+
+        done = 0
+        if use_graph and niter > 2:
+            try:
+                iteration()                             # eager first iteration (allocator warm-up), then capture the second
+                done = 1
+                g = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        iteration()
+                torch.cuda.current_stream().wait_stream(side)
+                for _ in range(niter - 1):
+                    g.replay()
+                done = niter
+            except RuntimeError:                        # an op that cannot be captured on this build: finish eagerly
+                torch.cuda.synchronize()
+                done = int(idx.item())
+        for _ in range(done, niter):
+            iteration()
+        hist = losses.tolist() if history else None
+        return float(losses[-1]) if niter else float("inf"), hist
 
     # ---- initialisation (init_im_poses.py:82-181, 569-635) ----------------------------------------------------------------------
     @torch.no_grad()

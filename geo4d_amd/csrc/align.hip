@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int MAXS = 8;        // windows an image can belong to (stride 4, length 16 -> 4, + the duplicated tail window)
+constexpr int MAXS = 6;        // windows an image can belong to (stride 4, length 16 -> 4, + the duplicated tail window = 5)
 constexpr int IMG_SUMS = 14;   // dL/dR (9) | dL/dt (3) | dL/df (1) | loss (1)
 constexpr int SLOT_SUMS = 12;  // dL/d(sR) (9) | dL/d(st) (3)
 
@@ -133,6 +133,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ prm, cons
     prm[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
 }
 
+// the same with lr and the two bias corrections read from device memory (hyper = {lr, 1 - b1^t, sqrt(1 - b2^t)}): the whole
+// iteration can then live in one captured hipGraph whose per-iteration scalars are produced on the device
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ prm, const float* __restrict__ grad, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, const float* __restrict__ hyper, float b1, float b2,
+                                                       float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2];
+    const float g = grad[i];
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    prm[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+
 }  // namespace
 
 extern "C" size_t geo4d_align_workspace(int n_imgs, int n_slots, int H, int W, int chunk_pixels) {
@@ -149,7 +165,7 @@ extern "C" int geo4d_align_residual(const geo4d_align_t* pp, void* stream) {
         geo4d_set_error("align_residual: bad arguments (chunk_pixels must be a positive multiple of 256)");
         return GEO4D_EINVAL;
     }
-    if (p.max_slots_per_image > MAXS) { geo4d_set_error("align_residual: an image belongs to more than 8 windows"); return GEO4D_ENOTSUP; }
+    if (p.max_slots_per_image > MAXS) { geo4d_set_error("align_residual: an image belongs to more than 6 windows"); return GEO4D_ENOTSUP; }
     const int HW = p.H * p.W;
     const int nchunk = (HW + p.chunk_pixels - 1) / p.chunk_pixels;
     if (p.workspace_bytes < geo4d_align_workspace(p.n_imgs, p.n_slots, p.H, p.W, p.chunk_pixels)) { geo4d_set_error("align_residual: workspace too small"); return GEO4D_EINVAL; }
@@ -172,6 +188,15 @@ extern "C" int geo4d_adam_step(float* param, const float* grad, float* exp_avg, 
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, bc1, sqrtf(bc2));
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
+extern "C" int geo4d_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const float* hyper,
+                                   float beta1, float beta2, float eps, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) { geo4d_set_error("adam_step_dev: bad arguments"); return GEO4D_EINVAL; }
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       hyper, beta1, beta2, eps);
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;
 }

@@ -34,7 +34,10 @@ constexpr int smem_bytes() {
     return stage_bytes<BM, BN, WM, WN, ST>() + BM * MAXTAP * 4;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int ST>
+// HOT (bf16x3 only): the layout of the two operands is fixed at compile time to the one every conv / linear of the networks uses
+// (raw f32 activations, pre-split weights), so the fragment loop carries no per-fragment branch on the layout flags — measured:
+// uniform branches inside this K loop cost ~10 % (profiles/r02_gemm_x3.md). The generic build serves linear_t / batched GEMMs.
+template <typename T, int BM, int BN, int WM, int WN, int ST, bool HOT = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_conv_gemm_t p) {
     constexpr int NT = WM * WN * 64;              // 256 threads (4 waves) or 512 (8 waves: one 256x128 tile per CU)
     constexpr int EPC = Elem<T>::EPC;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     }
     // debug_ablate = 1 (tools/gemm_bench.py --ablate): treat raw f32 operands as if pre-split, i.e. skip the in-register split -
     // WRONG numbers, used only to measure what the split's VALU work costs
-    const bool a_split = p.a_split != 0 || p.debug_ablate == 1, w_split = p.w_split != 0 || p.debug_ablate == 1;
+    const bool a_split = HOT ? false : (p.a_split != 0 || p.debug_ablate == 1), w_split = HOT ? true : (p.w_split != 0 || p.debug_ablate == 1);
     auto compute_slab = [&](int buf) {
         const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
         const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
@@ -494,15 +497,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const geo4d_conv_gem
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int ST>
-int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
+template <typename T, int BM, int BN, int WM, int WN, int ST, bool HOT>
+int launch_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     constexpr int smem = smem_bytes<BM, BN, WM, WN, ST>();
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, ST>;
-    if (p.act == 2 && ((BN / WN / 32) & 1)) {
-        geo4d_set_error("conv_gemm: GEGLU needs wave tiles that are a multiple of 64 columns wide (this tile has an odd number of 32-column blocks)");
-        return GEO4D_EINVAL;
-    }
+    auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, ST, HOT>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
@@ -514,6 +513,23 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     dim3 grid((unsigned)tiles, (unsigned)p.batch, (unsigned)splits);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, p);
     GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int ST>
+int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
+    if (p.act == 2 && ((BN / WN / 32) & 1)) {
+        geo4d_set_error("conv_gemm: GEGLU needs wave tiles that are a multiple of 64 columns wide (this tile has an odd number of 32-column blocks)");
+        return GEO4D_EINVAL;
+    }
+    int rc;
+    if constexpr (IsX3<T>::value) {
+        if (p.w_split && !p.a_split && p.debug_ablate == 0) rc = launch_kernel<T, BM, BN, WM, WN, ST, true>(p, splits, stream);
+        else rc = launch_kernel<T, BM, BN, WM, WN, ST, false>(p, splits, stream);
+    } else {
+        rc = launch_kernel<T, BM, BN, WM, WN, ST, false>(p, splits, stream);
+    }
+    if (rc != GEO4D_OK) return rc;
     if (splits > 1) {
         const long total = (long)p.batch * p.M * (p.N / 8);
         hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);

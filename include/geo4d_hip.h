@@ -193,6 +193,10 @@ int geo4d_align_residual(const geo4d_align_t* p, void* stream);
  * replaces optimizer.step() of global_alignment_iter (dust3r/cloud_opt/base_opt_group.py:596-626) for the depth maps. */
 int geo4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                     float eps, int step, void* stream);
+/* The same with {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read from device memory (3 floats), so a captured hipGraph of one whole
+ * alignment iteration can be replayed while the schedule advances on the device. */
+int geo4d_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const float* hyper, float beta1,
+                        float beta2, float eps, void* stream);
 
 const char* geo4d_last_error(void);
 int geo4d_abi_version(void);
