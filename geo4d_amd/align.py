@@ -94,7 +94,7 @@ def lr_at(t, schedule, lr_base, lr_min):
 
 class GroupAligner:
     def __init__(self, groups, pred, conf, shared_focal=True, temporal_smoothing_weight=0.0, translation_weight=0.1, base_scale=0.5,
-                 conf_clamp=10.0, chunk_pixels=1024):
+                 conf_clamp=10.0, chunk_pixels=4096):
         """groups: list of G lists of S image indices; pred [G, S, H, W, 3], conf [G, S, H, W] fp32 on the HIP device."""
         if not pred.is_cuda:
             raise _lib.Geo4DNativeError("geo4d_amd.align.GroupAligner runs only on a HIP device (there is no CPU fallback)")

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void align_residual_kernel(const geo4d_align_t
             if (j >= ns) break;
             const int slot = p.slot_idx[s0 + j];
             const float* T = p.slot_trf + slot * 12;            // sR (9) | st (3) of the slot's window
-            const float* P = p.pred + ((long)slot * HW + px) * 3;
-            const float P0 = P[0], P1 = P[1], P2 = P[2];
+            const float3 Pv = *(const float3*)(p.pred + ((long)slot * HW + px) * 3);   // one 12-byte load per lane: 768 contiguous bytes per wave
+            const float P0 = Pv.x, P1 = Pv.y, P2 = Pv.z;
             const float r0 = X0 - (T[0] * P0 + T[1] * P1 + T[2] * P2 + T[9]);
             const float r1 = X1 - (T[3] * P0 + T[4] * P1 + T[5] * P2 + T[10]);
             const float r2 = X2 - (T[6] * P0 + T[7] * P1 + T[8] * P2 + T[11]);
