@@ -36,7 +36,7 @@ class ConvGemm(C.Structure):
         ("rowbias_div", C.c_int), ("bias_per_row", C.c_int), ("act", C.c_int),
         ("dtype", C.c_int), ("out_dtype", C.c_int), ("out_nchw", C.c_int), ("tile_hint", C.c_int),
         ("split_k", C.c_int), ("debug_ablate", C.c_int), ("alpha", C.c_float),
-        ("a_split", C.c_int), ("w_split", C.c_int),
+        ("a_split", C.c_int), ("w_split", C.c_int), ("gn_colsum", C.c_void_p),
     ]
 
 
@@ -46,7 +46,7 @@ class GroupNorm(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("ldx", C.c_long), ("ldy", C.c_long),
         ("F", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("frames_per_stat", C.c_int),
-        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float),
+        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p),
     ]
 
 

@@ -76,6 +76,14 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
             return GEO4D_EINVAL;
         }
     }
+    if (p.gn_colsum) {
+        const int oesz = p.out_dtype == GEO4D_F32 ? 4 : 2;
+        if ((p.M % 32) || (p.N % 8) || p.out_nchw || p.act == 2 || p.batch != 1 || p.split_k != 1 || ((p.ldo * oesz) % 16) || ((uintptr_t)p.O % 16) ||
+            ((uintptr_t)p.gn_colsum % 16) || (p.R && (((p.ldr * oesz) % 16) || ((uintptr_t)p.R % 16)))) {
+            geo4d_set_error("conv_gemm: gn_colsum needs M % 32 == 0, N % 8 == 0, a row-major 16-byte aligned output, batch 1, split_k = 1, no GEGLU");
+            return GEO4D_EINVAL;
+        }
+    }
     if (p.rowbias && p.rowbias_div <= 0) { geo4d_set_error("conv_gemm: rowbias_div"); return GEO4D_EINVAL; }
     if (p.batch > 65535) { geo4d_set_error("conv_gemm: batch too large"); return GEO4D_EINVAL; }
     if (!p.zeros || ((uintptr_t)p.zeros % 16)) { geo4d_set_error("conv_gemm: `zeros` must point at 16 zero bytes (16-byte aligned) in device memory"); return GEO4D_EINVAL; }

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     const long ldo = partial ? (long)p.N : p.ldo;
     const long obase = partial ? 0 : bz * p.o_bs;
     const bool geglu = !partial && p.act == 2;
+    const bool gn_on = !partial && p.gn_colsum != nullptr;
     const int oesz = odt == GEO4D_F32 ? 4 : 2;
     const int nout = geglu ? (p.N >> 1) : p.N;
     const bool vec_ok = !p.out_nchw && ((ldo * oesz) & 15) == 0 && (nout & 7) == 0 && (((uintptr_t)O + obase * oesz) & 15) == 0 &&
@@ -421,6 +422,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // read back: 8 output elements per lane (two 16-byte LDS reads)
+            float cs[8], cq[8];                      // GroupNorm column sums of this 32-row block (gn_colsum)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
             for (int rr = lr; rr < 32; rr += rows_per_pass) {
                 const int mo = m_w0 + a * 32 + rr;
                 const int n = ocol_w0 + cg * gcols + lc * 8;
@@ -455,6 +459,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
                         for (int j = 0; j < 8; ++j) e[j] += r[j];
                     }
                     *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<f16_t>(e);
+                }
+                if (gn_on) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { cs[j] += e[j]; cq[j] += e[j] * e[j]; }
+                }
+            }
+            if (gn_on) {
+                // per-column sum / sum of squares over the 32 rows of this block: lanes that hold the same 8 columns sit cpr apart
+                // (fixed-order xor butterfly: deterministic); the consumer GroupNorm merges the blocks (norm.hip gn_finalize_cols)
+                for (int o = cpr; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { cs[j] += __shfl_xor(cs[j], o); cq[j] += __shfl_xor(cq[j], o); }
+                }
+                const int mb = m_w0 + a * 32;
+                const int n = ocol_w0 + cg * gcols + lc * 8;
+                if (lane < cpr && mb < p.M && n < nout) {
+                    float* dst = p.gn_colsum + ((long)(mb >> 5) * nout + n) * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        f32x4 v = {cs[j], cq[j], cs[j + 1], cq[j + 1]};
+                        *(f32x4*)(dst + 2 * j) = v;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -133,6 +133,37 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// ---- GroupNorm pass 2': the same merge fed by the column sums the producing conv_gemm's epilogue wrote (gn_colsum): one item
+// per (32-row block, channel of the group) = (n = 32, mean = s / 32, M2 = q - s * mean); replaces pass 1 + pass 2 ----------------
+__global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __restrict__ colsum, int blocks_per_stat, int C, int G, float eps,
+                                                               float* __restrict__ stats, int nstat) {
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= nstat * G) return;
+    const int stat = unit / G, grp = unit - stat * G;
+    const int cpg = C / G;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    const int total = blocks_per_stat * cpg;
+    for (int i = lane; i < total; i += 64) {
+        const int rb = i / cpg, c = grp * cpg + (i - rb * cpg);
+        const f32x2 sq = *(const f32x2*)(colsum + (((long)stat * blocks_per_stat + rb) * C + c) * 2);
+        const float mb = sq[0] * (1.0f / 32.0f);
+        chan_merge(n, mean, m2, 32.f, mb, fmaxf(sq[1] - sq[0] * mb, 0.f));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
+        float n0 = n, a0 = mean, q0 = m2, n1 = nb, a1 = mb, q1 = qb;
+        if (lane & o) { n0 = nb; a0 = mb; q0 = qb; n1 = n; a1 = mean; q1 = m2; }
+        chan_merge(n0, a0, q0, n1, a1, q1);
+        n = n0; mean = a0; m2 = q0;
+    }
+    if (lane == 0) {
+        stats[((long)stat * G + grp) * 2 + 0] = mean;
+        stats[((long)stat * G + grp) * 2 + 1] = 1.0f / sqrtf(m2 / n + eps);
+    }
+}
+
 // ---- GroupNorm pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU -----------------
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
@@ -274,13 +305,19 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     float* part = (float*)p.workspace;
     float* stats = part + (size_t)p.F * nchunk * p.groups * 3;
     const size_t smem = (size_t)256 * 2 * EPC * 4 + (size_t)2 * p.C * 4;
-    hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
-                       R, nchunk, part);
-    GEO4D_CHECK_LAUNCH();
     const int nstat = p.F / p.frames_per_stat;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
-                       p.groups, p.eps, stats, nstat);
-    GEO4D_CHECK_LAUNCH();
+    if (p.colsum) {     // statistics already summed per 32-row block by the producing GEMM's epilogue: no pass over x
+        hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, p.colsum, p.frames_per_stat * (p.HW / 32),
+                           p.C, p.groups, p.eps, stats, nstat);
+        GEO4D_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
+                           R, nchunk, part);
+        GEO4D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
+                           p.groups, p.eps, stats, nstat);
+        GEO4D_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
                        p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act);
     GEO4D_CHECK_LAUNCH();
@@ -326,6 +363,7 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
     if ((p.ldx * esz) % 16 || (p.ldy * esz) % 16 || ((uintptr_t)p.x % 16) || ((uintptr_t)p.y % 16)) { geo4d_set_error("groupnorm: alignment"); return GEO4D_EINVAL; }
     if (p.workspace_bytes < geo4d_groupnorm_workspace(p.F, p.HW, p.groups, p.frames_per_stat)) { geo4d_set_error("groupnorm: workspace too small"); return GEO4D_EINVAL; }
     if (p.F > 65535) { geo4d_set_error("groupnorm: too many frames"); return GEO4D_EINVAL; }
+    if (p.colsum && ((p.HW % 32) || ((uintptr_t)p.colsum % 8))) { geo4d_set_error("groupnorm: colsum needs HW % 32 == 0"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {
         case GEO4D_F32: return groupnorm_typed<float>(p, s);

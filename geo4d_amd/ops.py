@@ -75,6 +75,7 @@ _TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning
 _TUNE = None
 _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1), (17, 2), (16, 2), (17, 8), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
+GN_FUSED_STATS = _os.environ.get("GEO4D_GN_FUSED", "1") != "0"   # GEMM epilogues emit the next GroupNorm's column sums
 DEBUG_ABLATE = 0       # tools/gemm_bench.py --ablate only
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
 
@@ -126,7 +127,7 @@ def workspace(device):
 def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout=1, Wout=1, KT=1, KH=1, KW=1,
               pt=0, ph=0, pw=0, stride=1, ups=1, bias=None, bias_per_row=False, rowbias=None, rowbias_div=0,
               residual=None, ldr=0, act=0, out_nchw=False, alpha=1.0, batch=1, a_bs=0, w_bs=0, o_bs=0, r_bs=0,
-              tile_hint=0, split_k=0, x3=False):
+              tile_hint=0, split_k=0, x3=False, gn_stats=False):
     """`lda` / `ldw` / `a_bs` / `w_bs` are strides of the tensors as passed (torch elements). bf16x3 mode is selected by the
     operands: f32 activations against a pre-split bf16 weight (either side), or two f32 operands with `x3=True`."""
     lib = _lib.load()
@@ -166,6 +167,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.alpha, p.split_k = alpha, split_k
     p.debug_ablate = DEBUG_ABLATE
     p.a_split, p.w_split = int(a_split), int(w_split)
+    p.gn_colsum = 0
     ws, zeros = workspace(a.device)
     p.workspace, p.workspace_bytes, p.zeros = ws.data_ptr(), ws.numel(), zeros.data_ptr()
 
@@ -181,6 +183,14 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
+    if gn_stats and GN_FUSED_STATS and M % 32 == 0 and N % 8 == 0 and act != 2 and not out_nchw and batch == 1 and split_k <= 1 \
+            and out.dim() == 2 and out.shape[0] == M and out.data_ptr() % 16 == 0 and (ldo * out.element_size()) % 16 == 0 \
+            and (residual is None or (residual.data_ptr() % 16 == 0 and (ldr * out.element_size()) % 16 == 0)):
+        # the consumer GroupNorm's statistics pass, for free: per 32-row block and column (sum, sum of squares) from the epilogue
+        split_k = 1
+        cs = torch.empty((M // 32, N, 2), device=out.device, dtype=torch.float32)
+        p.gn_colsum = cs.data_ptr()
+        out._gn_colsum = cs
     if GEMM_TIMELINE is not None:     # bench.py's per-launch HIP-event timeline of the dominant kernel (never on while capturing)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -192,7 +202,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     return out
 
 
-def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0, split_k=0):
+def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0, split_k=0, gn_stats=False):
     """x [M, K] (row pitch free), w packed [N, K]; GEGLU (act=2) returns [M, N/2]."""
     M, K = x.shape
     N = w.shape[0]
@@ -201,11 +211,11 @@ def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, a
         out = torch.empty((M, N // 2 if act == 2 else N), device=x.device, dtype=out_dtype or x.dtype)
     return conv_gemm(x, w, out, M=M, N=N, K=K, Cin=K, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), bias=bias,
                      residual=residual, ldr=_ld(residual) if residual is not None else 0, act=act, alpha=alpha,
-                     tile_hint=tile_hint, split_k=split_k)
+                     tile_hint=tile_hint, split_k=split_k, gn_stats=gn_stats)
 
 
 def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1, T=1, rowbias=None, rowbias_div=0,
-           residual=None, act=0, out=None, out_dtype=None, out_nchw=False, nchw_channels=None, tile_hint=0, split_k=0):
+           residual=None, act=0, out=None, out_dtype=None, out_nchw=False, nchw_channels=None, tile_hint=0, split_k=0, gn_stats=False):
     """x tokens [F*Hin*Win, Cin]; w packed [N, KH*KW*Cin]. Output tokens [F*Hout*Wout, N], or with out_nchw a
     [B, C, T, Hout, Wout] tensor (`out` may be a channel-offset view of a wider tensor with `nchw_channels` channels).
     `pad_end` = extra zero rows / columns at the bottom / right only (ae_modules.py:102-106 pads (0,1,0,1) before its
@@ -227,11 +237,11 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1
               Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=KH, KW=KW, ph=pad, pw=pad, stride=stride, ups=ups, bias=bias,
               rowbias=rowbias, rowbias_div=rowbias_div, residual=residual,
               ldr=_ld(residual) if residual is not None else 0, act=act, out_nchw=out_nchw, tile_hint=tile_hint,
-              split_k=split_k)
+              split_k=split_k, gn_stats=gn_stats)
     return out, Hout, Wout
 
 
-def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None):
+def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None, gn_stats=False):
     """nn.Conv3d kernel (3,1,1), padding (1,0,0) on tokens [(b t) hw, C]; w packed [N, 3*C]."""
     Cin = x.shape[1]
     N = w.shape[0]
@@ -241,7 +251,7 @@ def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None):
         out = torch.empty((M, N), device=x.device, dtype=x.dtype)
     return conv_gemm(x, w, out, M=M, N=N, K=3 * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), T=T, Hin=HW, Win=1,
                      Hout=HW, Wout=1, KT=3, pt=1, bias=bias, residual=residual,
-                     ldr=_ld(residual) if residual is not None else 0)
+                     ldr=_ld(residual) if residual is not None else 0, gn_stats=gn_stats)
 
 
 def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias_per_row=False, alpha=1.0, x3=False):
@@ -270,6 +280,8 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     p.ldx, p.ldy = _ld(x), _ld(out)
     p.F, p.HW, p.C, p.groups, p.frames_per_stat = F, HW, Cc, groups, frames_per_stat
     p.act, p.dtype, p.eps = int(silu), dt_code(x.dtype), eps
+    cs = getattr(x, "_gn_colsum", None)     # column sums left on this very tensor object by the GEMM that produced it
+    p.colsum = cs.data_ptr() if (cs is not None and HW % 32 == 0 and tuple(cs.shape) == (F * HW // 32, Cc, 2)) else 0
     _lib.check(lib.geo4d_groupnorm(C.byref(p), _stream()), "geo4d_groupnorm")
     return out
 

@@ -394,15 +394,15 @@ class UNetModel(ParamTree):
         a = ops.groupnorm(h, *e["gn1"], F=F_, HW=HW, eps=1e-5, silu=True)
         lo, hi = e["emb"]
         h1, _, _ = ops.conv2d(a, e["w1"], e["b1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, rowbias=emb_all[:, lo:hi],
-                              rowbias_div=T * HW)
+                              rowbias_div=T * HW, gn_stats=True)      # gn_stats: the epilogue sums the next GroupNorm's statistics
         a = ops.groupnorm(h1, *e["gn2"], F=F_, HW=HW, eps=1e-5, silu=True)
         skip = ops.linear(h, *e["skip"]) if "skip" in e else h
-        h2, _, _ = ops.conv2d(a, e["w2"], e["b2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip)
+        h2, _, _ = ops.conv2d(a, e["w2"], e["b2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True)
         if "tc" in e:
             y = h2
             for i, (gn, w, b) in enumerate(e["tc"]):
                 a = ops.groupnorm(y, *gn, F=F_, HW=HW, eps=1e-5, frames_per_stat=T, silu=True)
-                y = ops.conv_temporal(a, w, b, B=B, T=T, HW=HW, residual=h2 if i == 3 else None)
+                y = ops.conv_temporal(a, w, b, B=B, T=T, HW=HW, residual=h2 if i == 3 else None, gn_stats=True)
             h2 = y
         return h2
 
@@ -429,7 +429,7 @@ class UNetModel(ParamTree):
         att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
         x = self._ff(blk, x)
-        return ops.linear(x, *e["out"], residual=h)
+        return ops.linear(x, *e["out"], residual=h, gn_stats=True)
 
     def _temporal(self, e, L, h, B, T, H, W):
         F_, HW, C_, heads = B * T, H * W, L.inner, L.heads
@@ -440,7 +440,7 @@ class UNetModel(ParamTree):
             att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125)
             x = ops.linear(att, *blk[a + ".o"], residual=x)
         x = self._ff(blk, x)
-        return ops.linear(x, *e["out"], residual=h)
+        return ops.linear(x, *e["out"], residual=h, gn_stats=True)
 
     def _run(self, P, layers, h, emb_all, kv, B, T, H, W):
         for L in layers:
@@ -452,7 +452,7 @@ class UNetModel(ParamTree):
             elif L.kind == "temporal":
                 h = self._temporal(e, L, h, B, T, H, W)
             elif L.kind == "down":
-                h, H, W = ops.conv2d(h, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, stride=2, pad=1)
+                h, H, W = ops.conv2d(h, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, stride=2, pad=1, gn_stats=True)
             elif L.kind == "up":
                 h, H, W = ops.conv2d(h, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2)
         return h, H, W
@@ -490,7 +490,7 @@ class UNetModel(ParamTree):
         # tokens
         e0 = P[inputs[0][0].prefix]
         h = ops.tokens_from_ncthw(x.float().contiguous(), None if c_concat is None else c_concat.float().contiguous(), e0["cpad"], dt)
-        h, _, _ = ops.conv2d(h, e0["w"], e0["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1)
+        h, _, _ = ops.conv2d(h, e0["w"], e0["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True)
         if init_attn is not None:
             h = self._temporal(P[init_attn.prefix], init_attn, h, B, T, H, W)
         hs = [(h, H, W)]

@@ -229,10 +229,10 @@ class AutoencoderKL(ParamTree):
     # ---- kernels -------------------------------------------------------------------------------------------------
     def _resnet(self, e, x, F_, H, W):
         a = ops.groupnorm(x, *e["gn1"], F=F_, HW=H * W, eps=1e-6, silu=True)
-        h, _, _ = ops.conv2d(a, *e["c1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1)
+        h, _, _ = ops.conv2d(a, *e["c1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True)
         a = ops.groupnorm(h, *e["gn2"], F=F_, HW=H * W, eps=1e-6, silu=True)
         skip = ops.linear(x, *e["nin"]) if "nin" in e else x
-        out, _, _ = ops.conv2d(a, *e["c2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip)
+        out, _, _ = ops.conv2d(a, *e["c2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True)
         return out
 
     # fp32 score rows are materialised per chunk of frames (the batched GEMMs + row softmax below); the chunk is sized so the
@@ -268,7 +268,7 @@ class AutoencoderKL(ParamTree):
                                                   ops._stream()), "geo4d_softmax_rows")
             ops.batched_gemm(probs, vt[f0 * C_:(f0 + nf) * C_], o[f0 * N:(f0 + nf) * N], batch=nf, M=N, N=C_, K=Np, a_bs=N * Np,
                              b_bs=C_ * Np, o_bs=N * C_, x3=x3)
-        return ops.linear(o, *e["o"], residual=x)
+        return ops.linear(o, *e["o"], residual=x, gn_stats=True)
 
     def decoder_features(self, z):
         """z [n, 4, h, w] (already divided by scale_factor) -> feature tokens [n*H*W, feat_ch], H, W (pre norm_out)."""
@@ -277,14 +277,14 @@ class AutoencoderKL(ParamTree):
         dt = self.storage_dtype
         x = ops.tokens_from_ncthw(z.float().reshape(n, zc, 1, H, W).contiguous(), None, P["cpad"], dt)
         x = ops.linear(x, *P["pq"])
-        x, _, _ = ops.conv2d(x, *P["conv_in"], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1)
+        x, _, _ = ops.conv2d(x, *P["conv_in"], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True)
         for kind, p, ci, co in self.plan:
             if kind == "res":
                 x = self._resnet(P[p], x, n, H, W)
             elif kind == "attn":
                 x = self._attn(P[p], x, n, H, W)
             else:
-                x, H, W = ops.conv2d(x, *P[p], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2)
+                x, H, W = ops.conv2d(x, *P[p], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2, gn_stats=True)
         return x, H, W
 
     def _head(self, head, feat, F_, H, W, out, T, nchw_channels):

@@ -66,6 +66,10 @@ typedef struct geo4d_conv_gemm_t {
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */
+    float* gn_colsum;    /* optional [M/32][N][2] fp32: per 32-row block and output column, (sum, sum of squares) of the values this
+                            launch stores - the statistics pass of the GroupNorm that consumes O, produced for free by the epilogue
+                            (geo4d_groupnorm_t.colsum). Needs M % 32 == 0, N % 8 == 0, row-major 16-byte aligned output, batch 1,
+                            no GEGLU and no split-K. */
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);
 
@@ -81,6 +85,8 @@ typedef struct geo4d_groupnorm_t {
     int act;             /* 0 none, 1 SiLU / swish                                       */
     int dtype;
     float eps;
+    const float* colsum; /* optional: [F*HW/32][C][2] column sums written by the producing geo4d_conv_gemm (gn_colsum); when given
+                            (needs HW % 32 == 0) the pass over x that computes the statistics is skipped */
 } geo4d_groupnorm_t;
 size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat);
 int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);

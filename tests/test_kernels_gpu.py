@@ -422,3 +422,29 @@ def test_lds_dma_pipelines_are_race_free(dev, dtype):
     outs = [ops.conv2d(x, w, None, F=16, Hin=20, Win=32, KH=3, KW=3, pad=1, tile_hint=t, split_k=1)[0] for t in (1, 1, 1, 2, 3, 4, 11, 12, 12, 13, 13, 14, 14, 16, 16, 17, 17)]   # same split => same fp32 association
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "conv_gemm output depends on launch / tile shape"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(4, 64, 320, 1, 0), (4, 160, 640, 4, 11), (2, 2560, 320, 2, 16), (3, 96, 128, 1, 2)])
+def test_groupnorm_statistics_from_the_gemm_epilogue(dev, dtype, case):
+    """conv_gemm(gn_stats=True) leaves per-32-row-block column sums on its output; the GroupNorm that consumes that tensor skips
+    its statistics pass. Same result as the three-pass GroupNorm (to fp32 re-association) and as F.group_norm; every tile shape
+    writes every (block, column) exactly once; a residual and a bias are part of what is summed."""
+    from geo4d_amd import ops
+    F, HW, Cc, fps, tile = case
+    M, K = F * HW, 128
+    x, w = rnd((M, K), dev, dtype, 300), rnd((Cc, K), dev, dtype, 301, 0.1)
+    b, r = rnd((Cc,), dev, torch.float32, 302), rnd((M, Cc), dev, dtype, 303)
+    g, be = rnd((Cc,), dev, torch.float32, 304), rnd((Cc,), dev, torch.float32, 305)
+    h = ops.linear(x, w, b, residual=r, tile_hint=tile, gn_stats=True)
+    assert hasattr(h, "_gn_colsum") and h._gn_colsum.shape == (M // 32, Cc, 2)
+    cs_ref = torch.stack([h.float().reshape(M // 32, 32, Cc).sum(1), (h.float() ** 2).reshape(M // 32, 32, Cc).sum(1)], -1)
+    assert rel(h._gn_colsum, cs_ref) < (2e-3 if dtype == torch.bfloat16 else 3e-4)      # sums of the un-rounded fp32 values
+    fused = ops.groupnorm(h, g, be, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)
+    plain = ops.groupnorm(h.clone(), g, be, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)     # the clone carries no sums
+    x5 = h.float().reshape(F // fps, fps, HW, Cc).permute(0, 3, 1, 2)
+    ref = TF.silu(TF.group_norm(x5, 32, g, be, 1e-5)).permute(0, 2, 3, 1).reshape(M, Cc)
+    check(f"groupnorm fused stats {case}", fused, ref, dtype, scale=2.0)
+    check(f"groupnorm fused vs three-pass {case}", fused, plain.float(), dtype, scale=1.0)
+    fused2 = ops.groupnorm(ops.linear(x, w, b, residual=r, tile_hint=tile, gn_stats=True), g, be, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)
+    assert torch.equal(fused, fused2), "fused-statistics GroupNorm must be run-to-run deterministic"
