@@ -137,14 +137,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // per (32-row block, channel of the group) = (n = 32, mean = s / 32, M2 = q - s * mean); replaces pass 1 + pass 2 ----------------
 __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __restrict__ colsum, int blocks_per_stat, int C, int G, float eps,
                                                                float* __restrict__ stats, int nstat) {
-    const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= nstat * G) return;
+    // one WORKGROUP per (stat, group): a 5-D GroupNorm at level 0 has 32 units of 12800 items each, too few and too long for one
+    // wave per unit (first version: slower than the statistics pass it replaced)
+    __shared__ float red[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = blockIdx.x;
     const int stat = unit / G, grp = unit - stat * G;
     const int cpg = C / G;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     const int total = blocks_per_stat * cpg;
-    for (int i = lane; i < total; i += 64) {
+    for (int i = tid; i < total; i += 256) {
         const int rb = i / cpg, c = grp * cpg + (i - rb * cpg);
         const f32x2 sq = *(const f32x2*)(colsum + (((long)stat * blocks_per_stat + rb) * C + c) * 2);
         const float mb = sq[0] * (1.0f / 32.0f);
@@ -158,7 +160,11 @@ __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __re
         chan_merge(n0, a0, q0, n1, a1, q1);
         n = n0; mean = a0; m2 = q0;
     }
-    if (lane == 0) {
+    if (lane == 0) { red[wave][0] = n; red[wave][1] = mean; red[wave][2] = m2; }
+    __syncthreads();
+    if (tid == 0) {
+        n = red[0][0]; mean = red[0][1]; m2 = red[0][2];
+        for (int w2 = 1; w2 < 4; ++w2) chan_merge(n, mean, m2, red[w2][0], red[w2][1], red[w2][2]);    // fixed order
         stats[((long)stat * G + grp) * 2 + 0] = mean;
         stats[((long)stat * G + grp) * 2 + 1] = 1.0f / sqrtf(m2 / n + eps);
     }
@@ -307,7 +313,7 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     const size_t smem = (size_t)256 * 2 * EPC * 4 + (size_t)2 * p.C * 4;
     const int nstat = p.F / p.frames_per_stat;
     if (p.colsum) {     // statistics already summed per 32-row block by the producing GEMM's epilogue: no pass over x
-        hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, p.colsum, p.frames_per_stat * (p.HW / 32),
+        hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nstat * p.groups), dim3(256), 0, s, p.colsum, p.frames_per_stat * (p.HW / 32),
                            p.C, p.groups, p.eps, stats, nstat);
         GEO4D_CHECK_LAUNCH();
     } else {

@@ -128,7 +128,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.geo4d_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define GEO4D_ABI_VERSION (\d+)", hdr).group(1))
-    assert ctypes.sizeof(_lib.ConvGemm) == 9 * 8 + 9 * 8 + 27 * 4 + 4 + 2 * 4, ctypes.sizeof(_lib.ConvGemm)
+    assert ctypes.sizeof(_lib.ConvGemm) == 9 * 8 + 9 * 8 + 27 * 4 + 4 + 2 * 4 + 8, ctypes.sizeof(_lib.ConvGemm)   # + gn_colsum
     assert lib.geo4d_groupnorm_workspace(16, 2560, 32, 1) == (16 * 64 * 32 * 3 + 16 * 32 * 2) * 4
     # argument validation happens on the host before any launch: bad descriptors return -EINVAL with a message
     p = _lib.ConvGemm()

@@ -431,6 +431,16 @@ def test_groupnorm_statistics_from_the_gemm_epilogue(dev, dtype, case):
     its statistics pass. Same result as the three-pass GroupNorm (to fp32 re-association) and as F.group_norm; every tile shape
     writes every (block, column) exactly once; a residual and a bias are part of what is summed."""
     from geo4d_amd import ops
+    monkey = ops.GN_FUSED_STATS
+    ops.GN_FUSED_STATS = True                 # the switch is off by default (ops.py): the path is exercised here regardless
+    try:
+        _fused_stats_case(dev, dtype, case)
+    finally:
+        ops.GN_FUSED_STATS = monkey
+
+
+def _fused_stats_case(dev, dtype, case):
+    from geo4d_amd import ops
     F, HW, Cc, fps, tile = case
     M, K = F * HW, 128
     x, w = rnd((M, K), dev, dtype, 300), rnd((Cc, K), dev, dtype, 301, 0.1)
