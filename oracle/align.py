@@ -14,9 +14,17 @@ PINNED: tests/golden/align_tiny.pt holds the loss, its gradients and the result 
 global_alignment_loop, produced by the reference classes imported from /root/reference with ONLY `roma` replaced by these
 restatements (and unrelated absent packages mocked) — tests/golden/generate.py align.
 
-Not restated (and not built in geo4d_amd/align.py): the inverse-depth and trajectory terms that the reference switches on at
-iteration `depth_traj_start_iter` (they need its 5000-iteration LAD fit and evo's trajectory alignment), and the RANSAC-PnP based
-initialisation (cv2.solvePnPRansac is not reproducible; geo4d_amd initialises poses from the Plücker cameras of N2 instead).
+The two terms the reference switches on at iteration `depth_traj_start_iter` (optimizer_group.py:470-512) are restated below:
+  * inverse-depth term + its `_set_st_depth` start-up (:333-372): per window, a least-absolute-deviation fit of (s, t) by
+    dust3r/depth_eval.py's `absolute_value_scaling2` (:112-145, Adam on sum |s p + t - g|, median-ratio start :218-221) and the
+    delta < 1.25 acceptance metric (:283-304). PINNED on the reference's own `depth_evaluation` and on `forward` (align_tiny.pt).
+  * trajectory term + `_set_traj` (:242-268): needs `evo` (unpinned in requirements.txt, ABSENT here) for PoseTrajectory3D.align_origin
+    and the RPE rotation metric; both are restated from evo's published definitions (align_origin: P = ref_0 est_0^-1 applied on
+    the left of every pose; RPE(delta = 1 frame, all pairs) rotation_angle_deg: angle of (Q_i^-1 Q_{i+1})^-1 (P_i^-1 P_{i+1}), rmse).
+    PARITY UNPINNED for those two functions; the loss term itself (relative_pose_loss on the transformed trajectory) is pinned
+    through `forward` with the restated functions substituted for evo's.
+Not restated (and not built in geo4d_amd/align.py): the RANSAC-PnP based initialisation (cv2.solvePnPRansac is not reproducible;
+geo4d_amd initialises poses from the Plücker cameras of N2 instead).
 """
 import math
 
@@ -95,10 +103,22 @@ def relative_pose_loss(RT1, RT2, translation_weight):
     return rot + torch.norm(rel[:, :3, 3], dim=1) * translation_weight
 
 
+def rigid_inverse(M):
+    R, t = M[..., :3, :3], M[..., :3, 3]
+    out = torch.zeros_like(M)
+    out[..., :3, :3] = R.transpose(-1, -2)
+    out[..., :3, 3] = -(R.transpose(-1, -2) @ t[..., None])[..., 0]
+    out[..., 3, 3] = 1
+    return out
+
+
 def alignment_loss(P, data, temporal_smoothing_weight=0.0, translation_weight=0.1, focal_break=20.0, base_scale=0.5,
-                   norm_pw_scale=True, conf_clamp=10.0):
-    """P: dict(im_depthmaps [n, HW] (log depth), im_poses [n, 7], im_focals [1 or n, 1] (focal_break * log f), pw_poses [G, 8]);
-    data: dict(pred [G*S, HW, 3], conf [G*S, HW], e_all int64 [G*S] image of every (group, slot), H, W)."""
+                   norm_pw_scale=True, conf_clamp=10.0, state=None):
+    """P: dict(im_depthmaps [n, HW] (log depth), im_poses [n, 7], im_focals [1 or n, 1] (focal_break * log f), pw_poses [G, 8]
+    [, s_depth [G, 1], t_depth [G, 1], traj_align_poses [G, 8]]);
+    data: dict(pred [G*S, HW, 3], conf [G*S, HW], e_all int64 [G*S] image of every (group, slot), H, W
+    [, invdepth [G*S, HW] predicted inverse depth, traj [G*S, 4, 4] per-window camera-to-world]);
+    state: None before `depth_traj_start_iter`; afterwards dict(invalid_depth_groups, valid_traj_groups) from start_depth_traj."""
     n, HW = P["im_depthmaps"].shape
     H, W = data["H"], data["W"]
     G = P["pw_poses"].shape[0]
@@ -124,9 +144,127 @@ def alignment_loss(P, data, temporal_smoothing_weight=0.0, translation_weight=0.
     total_area = float(data["pred"].shape[0] * HW)
     li = ((pts[data["e_all"]] - aligned).norm(dim=-1) * wgt).sum() / total_area
     loss = li
+    if state is not None and data.get("invdepth") is not None:
+        # optimizer_group.py:470-494: | 1 / (depth + 1e-6) - (s_g q + t_g) | where q > 0.05 and the window's fit was accepted, x 2
+        inv = 1.0 / (P["im_depthmaps"].exp() + 1e-6)
+        s = P["s_depth"].unsqueeze(1).repeat(1, S, 1).reshape(-1, 1)
+        t = P["t_depth"].unsqueeze(1).repeat(1, S, 1).reshape(-1, 1)
+        w = (data["invdepth"] > 0.05).float().reshape(G, S, HW).clone()
+        if len(state["invalid_depth_groups"]):
+            w[state["invalid_depth_groups"]] = 0
+        loss = loss + 2 * ((inv[data["e_all"]] - (data["invdepth"] * s + t)).abs() * w.reshape(G * S, HW)).sum() / total_area
+    if state is not None and data.get("traj") is not None and len(state["valid_traj_groups"]):
+        # optimizer_group.py:496-512
+        vg = state["valid_traj_groups"]
+        sc = P["traj_align_poses"][:, -1].exp()[vg]
+        RT = poses_to_matrix(P["traj_align_poses"])[vg]
+        tr = data["traj"].reshape(G, S, 4, 4)[vg]
+        moved = torch.cat([torch.cat([tr[:, :, :3, :3], tr[:, :, :3, 3:] * sc.reshape(-1, 1, 1, 1)], -1), tr[:, :, 3:]], -2)
+        moved = (RT[:, None] @ moved).reshape(-1, 4, 4)
+        idx = data["e_all"].reshape(G, S)[vg].reshape(-1)
+        loss = loss + 0.005 * relative_pose_loss(moved, im_poses[idx], translation_weight).sum()
     if temporal_smoothing_weight > 0:
         loss = loss + temporal_smoothing_weight * relative_pose_loss(im_poses[:-1], im_poses[1:], translation_weight).sum()
     return loss
+
+
+# ---- start-up of the inverse-depth term -------------------------------------------------------------------------------------------
+def lad_fit(pred, gt, lr, max_iters, tol=1e-6):
+    """depth_eval.py:218-221 + absolute_value_scaling2 :112-145: (s, t) minimising sum |s pred + t - gt| by Adam (default betas),
+    started at s = median(gt) / median(pred) (torch.median = the LOWER median), t = 0; stops when the loss repeats within tol."""
+    s = torch.tensor([(torch.median(gt) / torch.median(pred)).item()], requires_grad=True, dtype=pred.dtype)
+    t = torch.tensor([0.0], requires_grad=True, dtype=pred.dtype)
+    opt = torch.optim.Adam([s, t], lr=lr)
+    prev = None
+    with torch.enable_grad():
+        for _ in range(max_iters):
+            opt.zero_grad()
+            loss = torch.sum(torch.abs(s * pred + t - gt))
+            loss.backward()
+            opt.step()
+            if prev is not None and torch.abs(prev - loss) < tol:
+                break
+            prev = loss.item()
+    return s.detach().item(), t.detach().item()
+
+
+def delta_125(pred_aligned, gt):
+    """depth_eval.py:297-301: share of pixels whose ratio to the target is below 1.25 (prediction clamped at 1e-5 first)."""
+    p = torch.clamp(pred_aligned, min=1e-5)
+    return torch.mean((torch.maximum(p / gt, gt / p) < 1.25).float()).item()
+
+
+def fit_window_depth(q, g, custom_mask, lr, max_iters):
+    """depth_evaluation(q, g, max_depth=None, align_with_lad2=True, custom_mask=..., return_st=True) (depth_eval.py:147-330) reduced
+    to what _set_st_depth reads: fit over g > 0, delta < 1.25 over the custom mask inside it."""
+    m = g > 0
+    s, t = lad_fit(q[m], g[m], lr, max_iters)
+    mm = custom_mask[m]
+    return s, t, delta_125((s * q[m] + t)[mm], g[m][mm])
+
+
+@torch.no_grad()
+def set_st_depth(P, data, conf_clamp=10.0):
+    """optimizer_group.py:333-372: per window, fit (s, t) of its predicted inverse depth onto the inverse of the CURRENT depth maps;
+    retry at two smaller learning rates when fewer than 80 % of the pixels agree; windows under 30 % are dropped from the term."""
+    G = P["pw_poses"].shape[0]
+    inv = (1.0 / (P["im_depthmaps"].exp() + 1e-6))[data["e_all"]].reshape(G, -1)
+    q = data["invdepth"].reshape(G, -1)
+    cm = (data["conf"].clamp(max=conf_clamp).reshape(G, -1) > 0.5) & (q > 0.05)
+    invalid = []
+    for i in range(G):
+        s, t, best = fit_window_depth(q[i], inv[i], cm[i], 1e-2, 5000)
+        if best < 0.8:
+            for lr in (1e-4, 1e-3):
+                s2, t2, d2 = fit_window_depth(q[i], inv[i], cm[i], lr, 3000)
+                if d2 > best:
+                    s, t, best = s2, t2, d2
+        P["s_depth"].data[i], P["t_depth"].data[i] = s, t
+        if best < 0.3:
+            invalid.append(i)
+    return invalid
+
+
+# ---- start-up of the trajectory term (evo restated: see the header) ------------------------------------------------------------------
+def rotation_angle_deg(R):
+    return np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1.0, 1.0)))
+
+
+def align_origin_and_rpe(est, ref):
+    """est, ref: [S, 4, 4] float64 numpy. Returns (P, rpe_rot): P = ref_0 est_0^-1 (evo PosePath3D.align_origin), rpe_rot = rmse over
+    consecutive pairs of the angle (degrees) of (Q_i^-1 Q_{i+1})^-1 (P_i^-1 P_{i+1}) (evo main_rpe, rotation_angle_deg, delta 1)."""
+    P = ref[0] @ np.linalg.inv(est[0])
+    al = P[None] @ est
+    ang = []
+    for i in range(len(est) - 1):
+        E = np.linalg.inv(np.linalg.inv(ref[i]) @ ref[i + 1]) @ (np.linalg.inv(al[i]) @ al[i + 1])
+        ang.append(rotation_angle_deg(E[:3, :3]))
+    return P, float(np.sqrt(np.mean(np.square(ang))))
+
+
+@torch.no_grad()
+def set_traj(P, data, base_scale=0.5, norm_pw_scale=True):
+    """optimizer_group.py:242-268: move every window's predicted trajectory (translations scaled by the window's current scale) onto
+    the current cameras at its first frame; traj_align_poses_g = (that transform, log scale); windows whose relative-rotation error
+    stays below 4 degrees take part in the term."""
+    G = P["pw_poses"].shape[0]
+    S = data["pred"].shape[0] // G
+    im = poses_to_matrix(P["im_poses"])
+    scale = P["pw_poses"][:, -1].exp()
+    if norm_pw_scale:
+        scale = scale * (math.log(base_scale) - P["pw_poses"][:, -1].mean()).exp()
+    valid = []
+    for g in range(G):
+        tr = data["traj"].reshape(G, S, 4, 4)[g].clone()
+        tr[:, :3, 3] = tr[:, :3, 3] * scale[g]
+        ref = im[data["e_all"].reshape(G, S)[g]]
+        Pm, rpe_rot = align_origin_and_rpe(tr.double().numpy(), ref.double().numpy())
+        P["traj_align_poses"].data[g, :4] = rotmat_to_unitquat(torch.from_numpy(Pm[:3, :3])).float()
+        P["traj_align_poses"].data[g, 4:7] = signed_log1p(torch.from_numpy(Pm[:3, 3])).float()
+        P["traj_align_poses"].data[g, 7] = float(np.log(float(scale[g])))
+        if rpe_rot < 4:
+            valid.append(g)
+    return valid
 
 
 def lr_at(t, schedule, lr_base, lr_min):
@@ -137,16 +275,24 @@ def lr_at(t, schedule, lr_base, lr_min):
     raise ValueError(schedule)
 
 
-def alignment_loop(P, data, niter, lr=0.01, lr_min=1e-3, schedule="cosine", **loss_kw):
-    """global_alignment_loop (base_opt_group.py:553-626) on the restated loss: optimises P in place, returns the loss history."""
+def alignment_loop(P, data, niter, lr=0.01, lr_min=1e-3, schedule="cosine", depth_traj_start_iter=150, **loss_kw):
+    """global_alignment_loop (base_opt_group.py:553-626) on the restated loss: optimises P in place, returns the loss history.
+    Parameters that have not received a gradient yet (s_depth, t_depth, traj_align_poses before the start iteration) are skipped by
+    torch.optim.Adam, so their moments and bias corrections start when their terms do - as in the reference."""
     params = [p for p in P.values() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.9))
     hist = []
+    state = None
+    has_extra = data.get("invdepth") is not None or data.get("traj") is not None
     for it in range(niter):
         for g in opt.param_groups:
             g["lr"] = lr_at(it / niter, schedule, lr, lr_min)
         opt.zero_grad()
-        loss = alignment_loss(P, data, **loss_kw)
+        if has_extra and it == depth_traj_start_iter:
+            state = dict(invalid_depth_groups=set_st_depth(P, data, loss_kw.get("conf_clamp", 10.0)) if data.get("invdepth") is not None else [],
+                         valid_traj_groups=set_traj(P, data, loss_kw.get("base_scale", 0.5), loss_kw.get("norm_pw_scale", True))
+                         if data.get("traj") is not None else [])
+        loss = alignment_loss(P, data, state=state, **loss_kw)
         loss.backward()
         opt.step()
         hist.append(float(loss))

@@ -257,3 +257,76 @@ def test_alignment_oracle_vs_reference_optimizer():
     R, T, s = oalign.rigid_points_registration(g["pred"][1][:3].reshape(-1, 3), g["pred"][0][1:].reshape(-1, 3),
                                                weights=(g["conf"][1][:3] * g["conf"][0][1:]).reshape(-1), compute_scaling=True)
     assert torch.allclose(R, r["R"], atol=1e-5) and torch.allclose(T, r["T"], atol=1e-5) and abs(float(s) - float(r["s"])) < 1e-5
+
+
+def _align_data(g, extra=True):
+    G_, S, H, W = g["pred"].shape[:4]
+    data = dict(pred=g["pred"].reshape(G_ * S, H * W, 3), conf=g["conf"].reshape(G_ * S, H * W), H=H, W=W,
+                e_all=torch.tensor([i for grp in g["groups"] for i in grp]))
+    if extra:
+        d = g["depth_traj"]
+        data["invdepth"] = d["invdepth"].reshape(G_ * S, H * W)
+        data["traj"] = d["traj"].reshape(G_ * S, 4, 4)
+    return data
+
+
+def test_alignment_depth_fit_vs_reference_depth_evaluation():
+    """N1 start-up of the inverse-depth term: oracle lad_fit / delta_125 vs the reference's own dust3r.depth_eval.depth_evaluation
+    (align_with_lad2, return_st) on three windows of the synthetic scene (tests/golden/generate.py align)."""
+    from oracle import align as oalign
+    g = torch.load(os.path.join(G, "align_tiny.pt"), weights_only=False)
+    d = g["depth_traj"]
+    data = _align_data(g)
+    G_ = g["pred"].shape[0]
+    inv0 = (1.0 / (d["init"]["im_depthmaps"].exp() + 1e-6))[data["e_all"]].reshape(G_, -1)
+    q = data["invdepth"].reshape(G_, -1)
+    cm = (data["conf"].clamp(max=10).reshape(G_, -1) > 0.5) & (q > 0.05)
+    for ref in d["lad"]:
+        i = ref["group"]
+        s, t, delta = oalign.fit_window_depth(q[i], inv0[i], cm[i], ref["lr"], ref["iters"])
+        print("LAD window", i, (s, t, delta), (ref["s"], ref["t"], ref["delta"]))
+        assert abs(s - ref["s"]) < 2e-4 * max(1, abs(ref["s"])) and abs(t - ref["t"]) < 2e-4 and abs(delta - ref["delta"]) < 1e-6
+
+
+def test_alignment_oracle_depth_and_trajectory_terms_vs_reference():
+    """N1 with the inverse-depth and trajectory terms on from iteration 10 of 40: parameters after the reference's own loop (its
+    _set_st_depth incl. the retry path, _set_traj with evo's two functions replaced by the oracle's restatements), which windows
+    take part, and the full objective's value and gradients at the end point."""
+    from oracle import align as oalign
+    g = torch.load(os.path.join(G, "align_tiny.pt"), weights_only=False)
+    d = g["depth_traj"]
+    data = _align_data(g)
+    G_ = g["pred"].shape[0]
+    kw = dict(temporal_smoothing_weight=g["kw"]["temporal_smoothing_weight"], translation_weight=g["kw"]["translation_weight"])
+    P = {k: v.clone().requires_grad_(True) for k, v in d["init"].items()}
+    P["s_depth"] = torch.ones(G_, 1, requires_grad=True)
+    P["t_depth"] = torch.zeros(G_, 1, requires_grad=True)
+    P["traj_align_poses"] = torch.randn(G_, 8).requires_grad_(True)
+    # (a) the two start-up routines from the state the reference's saw at iteration `start`
+    su = d["startup"]
+    Q = {k: v.clone() for k, v in su["at_start"].items()}
+    Q.update(s_depth=torch.ones(G_, 1), t_depth=torch.zeros(G_, 1), traj_align_poses=torch.zeros(G_, 8))
+    invalid = oalign.set_st_depth(Q, data)
+    valid = oalign.set_traj(Q, data)
+    print("start-up s", Q["s_depth"].flatten().tolist(), su["st"]["s"].flatten().tolist())
+    assert invalid == su["st"]["invalid"] and valid == su["traj"]["valid"]
+    assert (Q["s_depth"] - su["st"]["s"]).abs().max() < 3e-4 and (Q["t_depth"] - su["st"]["t"]).abs().max() < 3e-4
+    tq, rq = Q["traj_align_poses"], su["traj"]["poses"]
+    sign = torch.sign((tq[:, :4] * rq[:, :4]).sum(1, keepdim=True))                     # q and -q are the same rotation
+    assert (tq[:, :4] * sign - rq[:, :4]).abs().max() < 1e-5 and (tq[:, 4:] - rq[:, 4:]).abs().max() < 1e-5
+    # (b) the whole loop. The L1 terms make single entries jump by one Adam step when a residual changes sign, so the end point is
+    # compared robustly: median deviation, and the share of entries within 5e-3
+    hist = oalign.alignment_loop(P, data, d["niter"], lr=g["lr"], lr_min=g["lr_min"], schedule=g["schedule"], depth_traj_start_iter=d["start"], **kw)
+    assert abs(hist[-1] - d["loss_final"]) < 2e-3 * d["loss_final"], (hist[-1], d["loss_final"])
+    for k in P:
+        dev_ = (P[k].detach() - d["after"][k]).abs()
+        print("after loop", k, float(dev_.median()), float(dev_.max()))
+        assert dev_.median() < 2e-3 and dev_.max() < 5e-2 and (dev_.numel() < 64 or (dev_ < 5e-3).float().mean() > 0.97), (k, float(dev_.median()), float(dev_.max()))
+    state = dict(invalid_depth_groups=d["invalid_depth_groups"], valid_traj_groups=d["valid_traj_groups"])
+    P = {k: v.clone().requires_grad_(True) for k, v in d["after"].items()}
+    loss = oalign.alignment_loss(P, data, state=state, **kw)
+    loss.backward()
+    assert abs(float(loss) - d["loss_at_after"]) < 1e-5 * abs(d["loss_at_after"]), (float(loss), d["loss_at_after"])
+    for k in P:
+        if d["grads_at_after"][k] is not None:
+            assert rel(P[k].grad, d["grads_at_after"][k]) < 1e-4, (k, rel(P[k].grad, d["grads_at_after"][k]))
