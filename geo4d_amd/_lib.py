@@ -12,7 +12,7 @@ import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its o
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 
@@ -68,8 +68,9 @@ class Align(C.Structure):
         ("grad_logdepth", C.c_void_p), ("img_sums", C.c_void_p), ("slot_sums", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("img_part", C.c_void_p), ("slot_part", C.c_void_p),
+        ("invdepth", C.c_void_p), ("slot_st", C.c_void_p),
         ("n_imgs", C.c_int), ("n_slots", C.c_int), ("H", C.c_int), ("W", C.c_int), ("chunk_pixels", C.c_int), ("max_slots_per_image", C.c_int),
-        ("conf_clamp", C.c_float), ("inv_area", C.c_float),
+        ("conf_clamp", C.c_float), ("inv_area", C.c_float), ("depth_weight", C.c_float),
     ]
 
 
@@ -113,8 +114,16 @@ SIGNATURES = {
                                   C.c_int, C.c_void_p]),
     "geo4d_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                       C.c_void_p]),
+    "geo4d_lad_workspace": (C.c_size_t, [C.c_int, C.c_long]),
+    "geo4d_lad_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "geo4d_lower_median": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "geo4d_lad_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "geo4d_lad_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_float, C.c_float,
+                                  C.c_void_p, C.c_void_p]),
     "geo4d_last_error": (C.c_char_p, []),
     "geo4d_abi_version": (C.c_int, []),
+    "geo4d_abi_struct_size": (C.c_size_t, [C.c_int]),
 }
 
 _lib = None
@@ -142,6 +151,10 @@ def load():
         fn.argtypes = args
     if lib.geo4d_abi_version() != ABI_VERSION:
         raise Geo4DNativeError(f"ABI mismatch: library {lib.geo4d_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    for which, struct in enumerate((ConvGemm, GroupNorm, Attention, Align)):
+        if lib.geo4d_abi_struct_size(which) != C.sizeof(struct):
+            raise Geo4DNativeError(f"ABI mismatch: {struct.__name__} is {lib.geo4d_abi_struct_size(which)} bytes in the library, "
+                                   f"{C.sizeof(struct)} in the binding; rebuild")
     _lib = lib
     return lib
 

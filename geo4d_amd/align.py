@@ -18,8 +18,19 @@ confidence-weighted similarity registration (``roma.rigid_points_registration`` 
 come from registering every window to the chained cloud, depths are the z of the cloud in each camera. DEVIATION: the reference
 finds every camera by OpenCV RANSAC-PnP (cv2.solvePnPRansac — absent here and not reproducible); this module takes the per-window
 camera-to-world matrices that the Plücker ray maps already give (geo4d_amd/rays.py, N2) and a focal estimated from the first
-frame's point map. NOT built: the inverse-depth and trajectory terms the reference adds from iteration 150 on (its 5000-iteration
-LAD fit and evo's trajectory alignment).
+frame's point map.
+
+From iteration ``depth_traj_start_iter`` (150) on the reference adds two terms (optimizer_group.py:470-512), built here as well:
+  * inverse depth: ``2/A sum |1/(depth + 1e-6) - (s_g q + t_g)|`` over the pixels whose predicted inverse depth q exceeds 0.05, fused
+    into the SAME residual kernel (4 more bytes per slot-pixel). Its start-up ``_set_st_depth`` (:333-372) — per window a
+    5000-iteration Adam least-absolute-deviation fit of (s, t) started at a median ratio, scored by delta < 1.25, retried at two
+    smaller learning rates under 80 %, dropped under 30 % — runs as HIP kernels for all windows at once (csrc/align.hip: radix-select
+    medians, one launch per Adam iteration, one scoring pass); the reference runs ~6 torch kernels per iteration per window.
+  * trajectory: ``0.005 sum relative_pose_loss(T_g [R_k | e^l_g t_k], pose_i)`` over the windows whose predicted trajectory agrees
+    with the current cameras within 4 degrees of relative rotation after ``_set_traj`` (:242-268, evo's align_origin + RPE, restated:
+    16 4x4 matrices per window, host side); the term itself is tiny-tensor autograd like the smoothing term.
+s_depth / t_depth / traj_align_poses join Adam when their terms start (torch skips parameters without gradients, so their moments
+and bias corrections count from the start iteration — reproduced with a second hyper-parameter table).
 """
 import ctypes as C
 import math
@@ -94,8 +105,11 @@ def lr_at(t, schedule, lr_base, lr_min):
 
 class GroupAligner:
     def __init__(self, groups, pred, conf, shared_focal=True, temporal_smoothing_weight=0.0, translation_weight=0.1, base_scale=0.5,
-                 conf_clamp=10.0, chunk_pixels=4096):
-        """groups: list of G lists of S image indices; pred [G, S, H, W, 3], conf [G, S, H, W] fp32 on the HIP device."""
+                 conf_clamp=10.0, chunk_pixels=4096, inverse_depth=None, traj=None, depth_traj_start_iter=150):
+        """groups: list of G lists of S image indices; pred [G, S, H, W, 3], conf [G, S, H, W] fp32 on the HIP device;
+        inverse_depth [G, S, H, W(, 1)] (the decoded inverse-depth modality mapped to [0, 1]) and traj [G, S, 4, 4] (every window's
+        camera-to-world matrices in its own frame, N2) switch the two late terms on (pred_pts['inverse_depthmap'] / ['traj'],
+        scripts/evaluation/test_geo4d.py:498-501)."""
         if not pred.is_cuda:
             raise _lib.Geo4DNativeError("geo4d_amd.align.GroupAligner runs only on a HIP device (there is no CPU fallback)")
         self.lib = _lib.load()
@@ -125,9 +139,26 @@ class GroupAligner:
                   "pw_poses": torch.cat([z(G, 3), torch.ones(G, 1, device=self.dev), z(G, 4)], 1)}
         need = self.lib.geo4d_align_workspace(self.n, G * S, H, W, self.chunk)
         self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-        self._img_sums, self._slot_sums = z(self.n, 14), z(G * S, 12)
+        self._img_sums, self._slot_sums = z(self.n, 14), z(G * S, 14)
         self._grad_ld = z(self.n, H * W)
         self._pp = torch.tensor([W / 2, H / 2], device=self.dev)
+        self.invdepth = None if inverse_depth is None else inverse_depth.reshape(G * S, H * W).float().contiguous()
+        self.traj = None if traj is None else traj.reshape(G, S, 4, 4).float().to(self.dev)
+        self.start_iter = depth_traj_start_iter
+        self.state = None                        # after the start iteration: dict(invalid_depth_groups, valid_traj_groups)
+        self.slot_img = torch.tensor(e_all, dtype=torch.int32, device=self.dev)
+        self.e_all = torch.tensor(e_all, dtype=torch.long, device=self.dev)
+        if self.invdepth is not None:
+            self.P["s_depth"], self.P["t_depth"] = torch.ones(G, 1, device=self.dev), z(G, 1)
+        if self.traj is not None:
+            self.P["traj_align_poses"] = torch.cat([z(G, 3), torch.ones(G, 1, device=self.dev), z(G, 4)], 1)
+
+    def _late_keys(self):
+        """Parameters that receive gradients only once their term is on (torch.optim.Adam skips them until then)."""
+        if self.state is None:
+            return ()
+        keys = ("s_depth", "t_depth") if self.invdepth is not None else ()
+        return keys + (("traj_align_poses",) if self.traj is not None and len(self.state["valid_traj_groups"]) else ())
 
     # ---- parameter -> geometry (tiny device tensors, differentiable) -----------------------------------------------------------
     def get_focals(self):
@@ -171,8 +202,9 @@ class GroupAligner:
 
     # ---- one loss / gradient evaluation ---------------------------------------------------------------------------------------
     def loss_and_grads(self):
-        """Returns (loss 0-dim device tensor, dict of gradients shaped like self.P)."""
-        small = {k: self.P[k].detach().clone().requires_grad_(True) for k in ("im_poses", "im_focals", "pw_poses")}
+        """Returns (loss 0-dim device tensor, dict of gradients shaped like self.P; parameters of terms that are off are absent)."""
+        late = self._late_keys()
+        small = {k: self.P[k].detach().clone().requires_grad_(True) for k in ("im_poses", "im_focals", "pw_poses") + late}
         saved, self.P = self.P, dict(self.P, **small)
         try:
             R, t = self.get_im_poses()
@@ -189,20 +221,41 @@ class GroupAligner:
         a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
         a.n_imgs, a.n_slots, a.H, a.W, a.chunk_pixels, a.max_slots_per_image = self.n, self.G * self.S, self.H, self.W, self.chunk, self.max_slots
         a.conf_clamp, a.inv_area = self.conf_clamp, 1.0 / float(self.G * self.S * self.H * self.W)
+        depth_on = "s_depth" in late
+        if depth_on:
+            slot_st = torch.cat([small["s_depth"].detach(), small["t_depth"].detach(), self._depth_ok], 1)[self.slot_group].contiguous()
+            a.invdepth, a.slot_st, a.depth_weight = self.invdepth.data_ptr(), slot_st.data_ptr(), 2.0 * a.inv_area
         _lib.check(self.lib.geo4d_align_residual(C.byref(a), ops._stream()), "geo4d_align_residual")
         I = self._img_sums
         # slot sums come back in CSR (image-major) order: put them in slot order, then add the S frames of each window
-        Ssum = torch.zeros_like(self._slot_sums).index_copy_(0, self.slot_order, self._slot_sums).reshape(self.G, self.S, 12).sum(1)
+        Ssum = torch.zeros_like(self._slot_sums).index_copy_(0, self.slot_order, self._slot_sums).reshape(self.G, self.S, -1).sum(1)
         loss = I[:, 13].sum()
         # chain rule through the tiny parameter -> matrix maps: d loss = <dL/dR, dR> + <dL/dt, dt> + dL/df df + <dL/dsR, dsR> + <dL/dst, dst>
         surrogate = (I[:, :9].reshape(self.n, 3, 3) * R).sum() + (I[:, 9:12] * t).sum() + (I[:, 12:13] * f).sum() + \
             (Ssum[:, :9].reshape(self.G, 3, 3) * sR).sum() + (Ssum[:, 9:12] * st).sum()
+        if depth_on:
+            surrogate = surrogate + (Ssum[:, 12:13] * small["s_depth"]).sum() + (Ssum[:, 13:14] * small["t_depth"]).sum()
+        eye = torch.eye(3, device=self.dev)
+        if "traj_align_poses" in late:
+            # optimizer_group.py:496-512: T_g [R_k | e^l t_k] against the cameras of the window's images (rigid inverse written out)
+            vg, idx = self._traj_vg, self._traj_idx          # device index tensors made once at the start-up (capturable)
+            tap = small["traj_align_poses"].index_select(0, vg)
+            Ra, ta, sc = quat_to_rotmat(tap[:, :4]), signed_expm1(tap[:, 4:7]), tap[:, 7].exp()
+            Rk, tk = self._traj_R, self._traj_t
+            Rm = Ra[:, None] @ Rk
+            tm = (Ra[:, None] @ (tk * sc[:, None, None])[..., None])[..., 0] + ta[:, None]
+            Rm, tm = Rm.reshape(-1, 3, 3), tm.reshape(-1, 3)
+            rel_R = Rm.transpose(1, 2) @ R[idx]
+            rel_t = (Rm.transpose(1, 2) @ (t[idx] - tm)[:, :, None])[:, :, 0]
+            ltraj = 0.005 * (torch.norm(rel_R - eye, dim=(1, 2)) + torch.norm(rel_t, dim=1) * self.tw).sum()
+            surrogate = surrogate + ltraj
+            loss = loss + ltraj.detach()
         if self.tsw > 0 and self.n > 1:
             # relative_pose_loss (optimizer_group.py:529-541): inverse(RT1) @ RT2 with RT rigid, so inverse = [R^T | -R^T t]
             # (no batched LU on the device: keeps the iteration capturable)
             Rt = R[:-1].transpose(1, 2)
             rel_R, rel_t = Rt @ R[1:], (Rt @ (t[1:] - t[:-1])[:, :, None])[:, :, 0]
-            smooth = (torch.norm(rel_R - torch.eye(3, device=self.dev), dim=(1, 2)) + torch.norm(rel_t, dim=1) * self.tw).sum()
+            smooth = (torch.norm(rel_R - eye, dim=(1, 2)) + torch.norm(rel_t, dim=1) * self.tw).sum()
             surrogate = surrogate + self.tsw * smooth
             loss = loss + self.tsw * smooth.detach()
         surrogate.backward()
@@ -210,57 +263,157 @@ class GroupAligner:
         grads["im_depthmaps"] = self._grad_ld
         return loss, grads
 
+    # ---- start-up of the two late terms -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _lad_fit(self, target, active, lr, iters, ws):
+        G, n = self.G, self.S * self.H * self.W
+        st, counts = torch.empty(G, 2, device=self.dev), torch.zeros(G, 2, dtype=torch.int32, device=self.dev)
+        info = torch.empty(G, 2, device=self.dev)
+        act = None if active is None else torch.tensor(active, dtype=torch.uint8, device=self.dev)
+        _lib.check(self.lib.geo4d_lad_fit(self.invdepth.data_ptr(), target.data_ptr(), G, n, None if act is None else act.data_ptr(), lr, iters,
+                                          1e-6, st.data_ptr(), info.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "geo4d_lad_fit")
+        self.lad_steps = info[:, 0].tolist()                 # Adam steps each window took before the reference's stop test fired
+        _lib.check(self.lib.geo4d_lad_delta(self.invdepth.data_ptr(), target.data_ptr(), self.conf.data_ptr(), st.data_ptr(), G, n, 0.5,
+                                            self.conf_clamp, 0.05, counts.data_ptr(), ops._stream()), "geo4d_lad_delta")
+        c = counts.double().cpu()
+        return st, (c[:, 0] / c[:, 1]).tolist()
+
+    @torch.no_grad()
+    def _set_st_depth(self):
+        """optimizer_group.py:333-372. Sets s_depth / t_depth; returns the windows dropped from the term."""
+        G, S, HW = self.G, self.S, self.H * self.W
+        target = torch.empty(G * S, HW, device=self.dev)
+        _lib.check(self.lib.geo4d_lad_target(self.P["im_depthmaps"].data_ptr(), self.slot_img.data_ptr(), target.data_ptr(), G * S, HW, ops._stream()),
+                   "geo4d_lad_target")
+        ws = torch.empty(self.lib.geo4d_lad_workspace(G, S * HW), dtype=torch.uint8, device=self.dev)
+        st, best = self._lad_fit(target, None, 1e-2, 5000, ws)
+        retry = [1 if b < 0.8 else 0 for b in best]
+        if any(retry):
+            for lr in (1e-4, 1e-3):
+                st2, d2 = self._lad_fit(target, retry, lr, 3000, ws)
+                for g in range(G):
+                    if retry[g] and d2[g] > best[g]:
+                        st[g], best[g] = st2[g], d2[g]
+        self.P["s_depth"].copy_(st[:, :1])
+        self.P["t_depth"].copy_(st[:, 1:])
+        self.depth_delta = best
+        return [g for g in range(G) if best[g] < 0.3]
+
+    @torch.no_grad()
+    def _set_traj(self):
+        """optimizer_group.py:242-268 (evo's align_origin and RPE rotation restated: oracle/align.py header). Host side: G x S 4x4."""
+        R, t = self.get_im_poses()
+        im = np.tile(np.eye(4), (self.n, 1, 1))
+        im[:, :3, :3], im[:, :3, 3] = R.double().cpu().numpy(), t.double().cpu().numpy()
+        scale = self.get_pw_scale().double().cpu().numpy()
+        traj = self.traj.double().cpu().numpy()
+        valid = []
+        for g, grp in enumerate(self.groups):
+            est = traj[g].copy()
+            est[:, :3, 3] *= scale[g]
+            ref = im[grp]
+            Pm = ref[0] @ np.linalg.inv(est[0])
+            al = Pm[None] @ est
+            ang = []
+            for k in range(self.S - 1):
+                E = np.linalg.inv(np.linalg.inv(ref[k]) @ ref[k + 1]) @ (np.linalg.inv(al[k]) @ al[k + 1])
+                ang.append(np.degrees(np.arccos(np.clip((np.trace(E[:3, :3]) - 1) / 2, -1.0, 1.0))))
+            self.P["traj_align_poses"][g, :4] = rotmat_to_quat(torch.from_numpy(Pm[:3, :3])).to(self.dev)
+            self.P["traj_align_poses"][g, 4:7] = signed_log1p(torch.from_numpy(Pm[:3, 3])).float().to(self.dev)
+            self.P["traj_align_poses"][g, 7] = float(np.log(scale[g]))
+            if float(np.sqrt(np.mean(np.square(ang)))) < 4:
+                valid.append(g)
+        return valid
+
+    def start_depth_traj(self):
+        """What forward() does at epoch == depth_traj_start_iter (optimizer_group.py:470-503)."""
+        self.set_state(self._set_st_depth() if self.invdepth is not None else [], self._set_traj() if self.traj is not None else [])
+        return self.state
+
+    def set_state(self, invalid_depth_groups, valid_traj_groups):
+        """Which windows take part in the late terms (normally decided by start_depth_traj)."""
+        self.state = dict(invalid_depth_groups=list(invalid_depth_groups), valid_traj_groups=list(valid_traj_groups))
+        ok = torch.ones(self.G, 1)
+        ok[self.state["invalid_depth_groups"]] = 0
+        self._depth_ok = ok.to(self.dev)
+        if self.traj is not None and len(valid_traj_groups):
+            vg = torch.tensor(self.state["valid_traj_groups"], dtype=torch.long, device=self.dev)
+            self._traj_vg = vg
+            self._traj_idx = self.e_all.reshape(self.G, self.S).index_select(0, vg).reshape(-1)
+            self._traj_R, self._traj_t = self.traj.index_select(0, vg)[:, :, :3, :3].contiguous(), self.traj.index_select(0, vg)[:, :, :3, 3].contiguous()
+
     # ---- optimisation loop (base_opt_group.py:553-626) --------------------------------------------------------------------------
     def compute_global_alignment(self, niter=300, lr=0.01, lr_min=1e-3, schedule="cosine", history=False, use_graph=True):
         """Adam (betas 0.9 / 0.9, eps 1e-8, bias-corrected: torch.optim.Adam's arithmetic) under the reference's schedule. One
         iteration = fused residual kernel + tiny chain rule + fused Adam on the depth maps + Adam on the small parameters, with
         lr and the bias corrections read from device tables indexed by a device counter — so ONE captured hipGraph is replayed
-        `niter` times with no host work in between (`use_graph`; the eager loop runs the same kernels)."""
-        keys = ("im_poses", "im_focals", "pw_poses")
+        with no host work in between (`use_graph`; the eager loop runs the same kernels). With the late terms the loop is two such
+        phases around the start-up at iteration `depth_traj_start_iter` (which synchronises with the host once)."""
         b1 = b2 = 0.9
         eps = 1e-8
         steps = torch.arange(1, niter + 1, dtype=torch.float64)
-        table = torch.stack([torch.tensor([lr_at(it / niter, schedule, lr, lr_min) for it in range(niter)], dtype=torch.float64),
-                             1 - b1 ** steps, (1 - b2 ** steps).sqrt()], 1).float().to(self.dev)            # [niter, 3]
+        lrs = torch.tensor([lr_at(it / niter, schedule, lr, lr_min) for it in range(niter)], dtype=torch.float64)
+        table = torch.stack([lrs, 1 - b1 ** steps, (1 - b2 ** steps).sqrt()], 1).float().to(self.dev)            # [niter, 3]
+        has_late = self.invdepth is not None or self.traj is not None
+        start = min(self.start_iter, niter) if has_late else niter
+        lsteps = (steps - start).clamp_min(1)                                  # a late parameter's own step count
+        table_late = torch.stack([lrs, 1 - b1 ** lsteps, (1 - b2 ** lsteps).sqrt()], 1).float().to(self.dev)
         idx = torch.zeros((1,), dtype=torch.long, device=self.dev)
-        hyper = torch.zeros(3, device=self.dev)
-        mom = {k: (torch.zeros_like(self.P[k]), torch.zeros_like(self.P[k])) for k in ("im_depthmaps",) + keys}
+        hyper, hyper_late = torch.zeros(3, device=self.dev), torch.zeros(3, device=self.dev)
+        mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.P.items()}
         losses = torch.zeros(niter, device=self.dev)
 
         def iteration():
             hyper.copy_(table.index_select(0, idx)[0])
+            hyper_late.copy_(table_late.index_select(0, idx)[0])
             loss, grads = self.loss_and_grads()
             losses.index_copy_(0, idx, loss.reshape(1))
             d, (m, v) = self.P["im_depthmaps"], mom["im_depthmaps"]
             _lib.check(self.lib.geo4d_adam_step_dev(d.data_ptr(), grads["im_depthmaps"].data_ptr(), m.data_ptr(), v.data_ptr(), d.numel(),
                                                     hyper.data_ptr(), b1, b2, eps, ops._stream()), "geo4d_adam_step_dev")
-            for k in keys:                              # a few dozen numbers each: plain tensor ops, same formula
-                g, (m, v) = grads[k], mom[k]
+            late = self._late_keys()
+            for k in ("im_poses", "im_focals", "pw_poses") + late:   # a few dozen numbers each: plain tensor ops, same formula
+                g, (m, v), h = grads[k], mom[k], hyper_late if k in late else hyper
                 m.mul_(b1).add_(g, alpha=1 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1 - b2)
-                self.P[k].sub_((hyper[0] / hyper[1]) * m / (v.sqrt() / hyper[2] + eps))
+                self.P[k].sub_((h[0] / h[1]) * m / (v.sqrt() / h[2] + eps))
             idx.add_(1)
 
-        done = 0
-        if use_graph and niter > 2:
-            try:
-                iteration()                             # eager first iteration (allocator warm-up), then capture the second
-                done = 1
-                g = torch.cuda.CUDAGraph()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    with torch.cuda.graph(g, stream=side):
-                        iteration()
-                torch.cuda.current_stream().wait_stream(side)
-                for _ in range(niter - 1):
-                    g.replay()
-                done = niter
-            except RuntimeError:                        # an op that cannot be captured on this build: finish eagerly
-                torch.cuda.synchronize()
-                done = int(idx.item())
-        for _ in range(done, niter):
-            iteration()
+        def run(count):
+            done = 0
+            if use_graph and count > 2:
+                try:
+                    iteration()                             # eager first iteration (allocator warm-up), then capture the second
+                    done = 1
+                    g = torch.cuda.CUDAGraph()
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(g, stream=side):
+                            iteration()
+                    torch.cuda.current_stream().wait_stream(side)
+                    for _ in range(count - 1):          # capturing records, it does not run
+                        g.replay()
+                    done = count
+                except RuntimeError:                        # an op that cannot be captured on this build: finish eagerly
+                    torch.cuda.synchronize()
+                    done = None
+            return done
+
+        def run_phase(first, last):
+            done = run(last - first)
+            if done is None:
+                done = int(idx.item()) - first
+            for _ in range(done, last - first):
+                iteration()
+
+        if self.state is None:
+            run_phase(0, start)
+            if has_late and start < niter:
+                self.start_depth_traj()
+                run_phase(start, niter)
+        else:                                               # terms already started (a second call continues with them on)
+            run_phase(0, niter)
         hist = losses.tolist() if history else None
         return float(losses[-1]) if niter else float("inf"), hist
 

@@ -307,3 +307,12 @@ void geo4d_set_error(const char* msg) {
 }
 extern "C" const char* geo4d_last_error(void) { return g_err; }
 extern "C" int geo4d_abi_version(void) { return GEO4D_ABI_VERSION; }
+extern "C" size_t geo4d_abi_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(geo4d_conv_gemm_t);
+        case 1: return sizeof(geo4d_groupnorm_t);
+        case 2: return sizeof(geo4d_attention_t);
+        case 3: return sizeof(geo4d_align_t);
+        default: return 0;
+    }
+}

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEO4D_ABI_VERSION 2
+#define GEO4D_ABI_VERSION 3
 
 /* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
  * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
@@ -182,7 +182,11 @@ int geo4d_plucker_cameras(const float* ray, const float* moment, long channel_st
  * slot_idx[slot_ptr[i] .. slot_ptr[i+1]).  loss = inv_area * sum min(conf, conf_clamp) * | X_i - (sR_g P + st_g) |.
  *   pred [n_slots][H*W][3], conf [n_slots][H*W], logdepth / grad_logdepth [n_imgs][H*W]          (fp32, device)
  *   cams [n_imgs][16] = R (9, row-major) | t (3) | focal | ppx | ppy | 0      slot_trf [n_slots][12] = sR (9) | st (3)
- *   img_sums [n_imgs][14] = dL/dR (9) | dL/dt (3) | dL/dfocal | loss share     slot_sums [n_slots][12] = dL/d(sR) (9) | dL/d(st) (3)
+ *   img_sums [n_imgs][14] = dL/dR (9) | dL/dt (3) | dL/dfocal | loss share
+ *   slot_sums [n_slots][14] = dL/d(sR) (9) | dL/d(st) (3) | dL/ds_depth, dL/dt_depth (inverse-depth term; 0 when off), in CSR order
+ * Inverse-depth term (optimizer_group.py:470-494), fused into the same pass when invdepth != NULL:
+ *   loss += depth_weight * sum_{slot, pixel: q > 0.05} accepted_g * | 1 / (exp(logdepth) + 1e-6) - (s_g q + t_g) |
+ *   invdepth [n_slots][H*W] = q, slot_st [n_slots][3] = (s_g, t_g, accepted_g in {0, 1}); the reference's factor 2 / total area is depth_weight.
  * workspace: geo4d_align_workspace bytes. Deterministic (fixed-order reductions). */
 typedef struct geo4d_align_t {
     const float* pred; const float* conf; const float* logdepth; const float* cams; const float* slot_trf;
@@ -190,8 +194,9 @@ typedef struct geo4d_align_t {
     float* grad_logdepth; float* img_sums; float* slot_sums;
     void* workspace; size_t workspace_bytes;
     float* img_part; float* slot_part;   /* set by the library (views of workspace) */
+    const float* invdepth; const float* slot_st;   /* inverse-depth term (NULL: off), see below */
     int n_imgs, n_slots, H, W, chunk_pixels, max_slots_per_image;
-    float conf_clamp, inv_area;
+    float conf_clamp, inv_area, depth_weight;
 } geo4d_align_t;
 size_t geo4d_align_workspace(int n_imgs, int n_slots, int H, int W, int chunk_pixels);
 int geo4d_align_residual(const geo4d_align_t* p, void* stream);
@@ -204,8 +209,29 @@ int geo4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int geo4d_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const float* hyper, float beta1,
                         float beta2, float eps, void* stream);
 
+/* Start-up of the inverse-depth term (LightPointCloudGroupOptimizer._set_st_depth, optimizer_group.py:333-372, which calls
+ * dust3r/depth_eval.py depth_evaluation(align_with_lad2=True) :147-330 per window). All arrays fp32 on the device, windows
+ * contiguous: q / target / conf are [G][n], n = S * H * W.
+ *   geo4d_lad_target: target[slot][px] = 1 / (exp(logdepth[slot_img[slot]][px]) + 1e-6)                     (:336-337)
+ *   geo4d_lower_median: out[r] = torch.median(x[r]) (the LOWER median), bit-exact, by radix select; workspace rows * 260 * 4 bytes
+ *   geo4d_lad_fit: (s, t)[g] minimising sum | s q + t - target | by torch.optim.Adam's arithmetic (default betas), started at
+ *     s = median(target) / median(q), t = 0; a window stops when its loss repeats within tol (depth_eval.py:112-145, 218-221).
+ *     active (NULL = all): windows with 0 are left at their start values. st_out [G][2]; info_out (may be NULL) [G][2] = (steps, last loss).
+ *   geo4d_lad_delta: counts[g] = {#(max(a/target, target/a) < 1.25), #mask}, a = max(s q + t, 1e-5), mask = min(conf, conf_clamp) >
+ *     conf_thr and q > q_thr (:297-301 under _set_st_depth's custom mask :340-342). */
+size_t geo4d_lad_workspace(int G, long n);
+int geo4d_lad_target(const float* logdepth, const int* slot_img, float* target, int n_slots, int HW, void* stream);
+int geo4d_lower_median(const float* x, int rows, long n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int geo4d_lad_fit(const float* q, const float* target, int G, long n, const unsigned char* active, float lr, int max_iters, float tol,
+                  float* st_out, float* info_out, void* workspace, size_t workspace_bytes, void* stream);
+int geo4d_lad_delta(const float* q, const float* target, const float* conf, const float* st, int G, long n, float conf_thr,
+                    float conf_clamp, float q_thr, unsigned* counts, void* stream);
+
 const char* geo4d_last_error(void);
 int geo4d_abi_version(void);
+/* sizeof of the parameter structs as the LIBRARY was compiled (which: 0 conv_gemm, 1 groupnorm, 2 attention, 3 align; else 0):
+ * bindings compare it with their own layout at load time. */
+size_t geo4d_abi_struct_size(int which);
 
 #ifdef __cplusplus
 }
