@@ -300,7 +300,8 @@ def main():
                          "note": "achieved = algorithmic flops (sum of 2*M*N*K over the conv_gemm launches of ONE eager U-Net forward, each product "
                                  "counted once) / sum of their HIP-event durations on the launch stream (brackets include a split-K launch's reduce "
                                  "kernel and ~2 us of dispatch gap each; the rocprofv3 kernel trace in profiles/ gives the pure kernel time); "
-                                 "peak = dense MFMA peak of the operand type / MFMA passes per product",
+                                 "peak = dense MFMA peak of the operand type / MFMA passes per product; measured on this GPU (profiles/r02_mfma_probe_and_kloop.md): "
+                                 "a pure MFMA loop on uniform random bf16 operands reaches 0.71 of that peak, 0.64 with the LDS fragment reads of the tile",
                          "whole_step": {"achieved": achieved, "frac": passes * achieved / peak,
                                         "note": f"{tflop_step:.1f} algorithmic TFLOP per step (SURVEY §8d: {TFLOP_UNET_STEP} x S + "
                                                 f"{TFLOP_DECODE_FRAME} x T at 16x40x64, scaled) / measured step time, per GPU, products counted once"}},

@@ -11,7 +11,8 @@ import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its o
 #                              are invalid in the other: "no ROCm-capable device is detected" at the first launch).
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
+# GEO4D_HIP_LIB: load another build of the SAME library (A/B builds of a kernel: tools/gpu_r2k.sh); the ABI handshake below still applies
+LIB_PATH = os.environ.get("GEO4D_HIP_LIB") or os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
 ABI_VERSION = 3
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
