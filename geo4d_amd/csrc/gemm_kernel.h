@@ -374,6 +374,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
         const long rboff = (!partial && p.rowbias && m < p.M) ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
 #pragma unroll
         for (int cg = 0; cg < NG; ++cg) {
+            // the residual chunks this lane will add in the read-back below are requested BEFORE the block is staged, so the global
+            // round trip (a workgroup's epilogue overlaps with nothing: one workgroup per CU) runs under the 16 LDS writes and the
+            // fences instead of once per read-back row - measured: tail + epilogue were 12 % of a long-K workgroup's life
+            u32x4 rpre[4][2];
+            const bool has_res = !partial && p.R != nullptr;
+            if (has_res) {
+                const int n = ocol_w0 + cg * gcols + lc * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rr = lr + k * rows_per_pass;
+                    const int mo = m_w0 + a * 32 + rr;
+                    if (rr < 32 && mo < p.M && n < nout) {
+                        if (odt == GEO4D_F32) {
+                            const float* rp = (const float*)p.R + bz * p.r_bs + (long)mo * p.ldr + n;
+                            rpre[k][0] = *(const u32x4*)rp;
+                            rpre[k][1] = *(const u32x4*)(rp + 4);
+                        } else {
+                            rpre[k][0] = *(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)mo * p.ldr + n);
+                        }
+                    }
+                }
+            }
             if (geglu) {
                 if constexpr (BPG == 2) {
                     // packed GEGLU weights interleave value / gate in 32-column blocks: block 2j = value, 2j + 1 = gate
@@ -425,7 +447,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
             float cs[8], cq[8];                      // GroupNorm column sums of this 32-row block (gn_colsum)
 #pragma unroll
             for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
-            for (int rr = lr; rr < 32; rr += rows_per_pass) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = lr + k * rows_per_pass;
+                if (rr >= 32) break;
                 const int mo = m_w0 + a * 32 + rr;
                 const int n = ocol_w0 + cg * gcols + lc * 8;
                 if (mo >= p.M || n >= nout) continue;
@@ -434,27 +459,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
                 float e[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 const long oidx = obase + (long)mo * ldo + n;
                 if (odt == GEO4D_F32) {
-                    if (!partial && p.R) {
-                        const float* rp = (const float*)p.R + bz * p.r_bs + (long)mo * p.ldr + n;
-                        const f32x4 r0v = *(const f32x4*)rp, r1v = *(const f32x4*)(rp + 4);
+                    if (has_res) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { e[j] += r0v[j]; e[4 + j] += r1v[j]; }
+                        for (int j = 0; j < 4; ++j) { e[j] += __uint_as_float(rpre[k][0][j]); e[4 + j] += __uint_as_float(rpre[k][1][j]); }
                     }
                     f32x4 o0 = {e[0], e[1], e[2], e[3]}, o1 = {e[4], e[5], e[6], e[7]};
                     *(f32x4*)((float*)O + oidx) = o0;
                     *(f32x4*)((float*)O + oidx + 4) = o1;
                 } else if (odt == GEO4D_BF16) {
-                    if (p.R) {
+                    if (has_res) {
                         float r[8];
-                        chunk_to_f32<bf16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)mo * p.ldr + n), r);
+                        chunk_to_f32<bf16_t>(rpre[k][0], r);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) e[j] += r[j];
                     }
                     *(u32x4*)((unsigned short*)O + oidx) = f32_to_chunk<bf16_t>(e);
                 } else {
-                    if (p.R) {
+                    if (has_res) {
                         float r[8];
-                        chunk_to_f32<f16_t>(*(const u32x4*)((const unsigned short*)p.R + bz * p.r_bs + (long)mo * p.ldr + n), r);
+                        chunk_to_f32<f16_t>(rpre[k][0], r);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) e[j] += r[j];
                     }
