@@ -196,3 +196,35 @@ def test_weight_relayout_is_the_same_linear_map():
     assert torch.allclose(got, ref[:, :inner] * F.gelu(ref[:, inner:]), atol=1e-5)
     perm = pack.geglu_perm(inner)
     assert sorted(perm.tolist()) == list(range(2 * inner))
+
+
+def test_binding_refuses_a_library_with_another_struct_layout(monkeypatch):
+    """The ctypes mirror of every parameter struct is checked against the library's own sizeof at load time (and the version):
+    a stale binding fails at import instead of handing the GPU a struct with shifted fields."""
+    import ctypes
+    from geo4d_amd import _lib
+    lib = _lib.load()
+    for which, struct in enumerate((_lib.ConvGemm, _lib.GroupNorm, _lib.Attention, _lib.Align)):
+        assert lib.geo4d_abi_struct_size(which) == ctypes.sizeof(struct)
+    assert lib.geo4d_abi_struct_size(99) == 0
+
+    class Grown(ctypes.Structure):
+        _fields_ = list(_lib.Align._fields_) + [("extra", ctypes.c_void_p)]
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "Align", Grown)
+    with pytest.raises(_lib.Geo4DNativeError, match="Align is"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
+
+
+def test_library_path_override_fails_loudly(monkeypatch, tmp_path):
+    """GEO4D_HIP_LIB points the binding at another build; a missing file raises (no fallback to the default library)."""
+    import importlib
+    from geo4d_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.Geo4DNativeError, match="not found"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
