@@ -11,13 +11,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // MODE 2: 4 accumulators, chains of 3 on each (the bf16x3 pattern)    MODE 3: 4 accumulators, chains of 6
 // MODE 4: 16x16x32, 16 accumulators round-robin                       MODE 5: 16x16x32, chains of 4 on each of 16 accumulators
 template <int MODE, bool BAR>
-__global__ __launch_bounds__(512) void probe(float* out, int iters, int nwaves_active) {
+__global__ __launch_bounds__(512) void probe(float* out, int iters, int nwaves_active, const unsigned* src) {
     extern __shared__ float lds[];                      // sized by the launch so that ONE workgroup fits a CU (occupancy = nwaves_active / 4 per SIMD)
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) lds[0] = 0.f;
     if (wave >= nwaves_active) return;
     bf16x8 a, b;
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (threadIdx.x - i)); }
+    if (src) {                                          // operands from memory: uniform random bf16 in [-1, 1) (data-dependent MFMA rate)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        a = __builtin_bit_cast(bf16x8, *(const u32x4*)(src + (threadIdx.x & 511) * 4));
+        b = __builtin_bit_cast(bf16x8, *(const u32x4*)(src + 2048 + (threadIdx.x & 511) * 4));
+    } else {
+        for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (threadIdx.x - i)); }
+    }
     float r = 0.f;
     if constexpr (MODE <= 3) {
         f32x16 acc[4];
@@ -58,14 +64,14 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters, int nwaves_a
 }
 
 template <int MODE, bool BAR>
-void run(const char* name, float* out, int waves) {
+void run(const char* name, float* out, int waves, const unsigned* src = nullptr) {
     const int iters = 2000, blocks = 256 * 4;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     // BAR kernels run all 8 waves (a barrier with exited waves is fine on AMD, but keep it simple)
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<MODE, BAR>), dim3(blocks), dim3(waves * 64), 100 * 1024, 0, out, iters, waves);
+        hipLaunchKernelGGL((probe<MODE, BAR>), dim3(blocks), dim3(waves * 64), 100 * 1024, 0, out, iters, waves, src);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
     }
@@ -96,6 +102,27 @@ int main() {
         run<4, false>("16x16x32 16 accumulators round-robin", out, waves);
         run<5, false>("16x16x32 16 accumulators, chains of 4", out, waves);
     }
+    unsigned* src;
+    hipMalloc(&src, 4096 * 4);
+    {
+        static unsigned h[4096];
+        unsigned st = 12345u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (st >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f; };
+        for (int i = 0; i < 4096; ++i) {
+            float x = rnd(), y = rnd();
+            unsigned ux, uy;
+            __builtin_memcpy(&ux, &x, 4); __builtin_memcpy(&uy, &y, 4);
+            h[i] = (ux >> 16) | (uy & 0xffff0000u);
+        }
+        hipMemcpy(src, h, sizeof(h), hipMemcpyHostToDevice);
+    }
+    printf("-- uniform random bf16 operands in [-1, 1), 8 waves per CU\n");
+    run<1, false>("32x32x16 4 accumulators round-robin, RANDOM operands", out, 8, src);
+    run<3, false>("32x32x16 4 accumulators, chains of 6, RANDOM operands", out, 8, src);
+    run<4, false>("16x16x32 16 accumulators round-robin, RANDOM operands", out, 8, src);
+    run<5, false>("16x16x32 16 accumulators, chains of 4, RANDOM operands", out, 8, src);
+    run<4, false>("16x16x32 16 accumulators round-robin, RANDOM operands, 4 waves per CU", out, 4, src);
+    printf("-- constant operands again\n");
     run<2, true>("32x32x16 chains of 3 + s_barrier every 24 MFMAs", out, 8);
     run<1, true>("32x32x16 round-robin + s_barrier every 24 MFMAs", out, 8);
     run<4, true>("16x16x32 round-robin + s_barrier every 48 MFMAs", out, 8);
