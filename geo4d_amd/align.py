@@ -17,8 +17,9 @@ Initialisation follows ``init_im_poses.align_group`` / ``init_from_pts3d_group``
 confidence-weighted similarity registration (``roma.rigid_points_registration`` = weighted Umeyama, restated here), ``pw_poses``
 come from registering every window to the chained cloud, depths are the z of the cloud in each camera. DEVIATION: the reference
 finds every camera by OpenCV RANSAC-PnP (cv2.solvePnPRansac — absent here and not reproducible); this module takes the per-window
-camera-to-world matrices that the Plücker ray maps already give (geo4d_amd/rays.py, N2) and a focal estimated from the first
-frame's point map.
+camera-to-world matrices that the Plücker ray maps already give (geo4d_amd/rays.py, N2). The focals start, as in the reference,
+from the Weiszfeld estimate on every image's ray map (`estimate_focal_weiszfeld`, pinned on dust3r.post_process; the reference then
+lets PnP pick among that value and +-3 % of the image size).
 
 From iteration ``depth_traj_start_iter`` (150) on the reference adds two terms (optimizer_group.py:470-512), built here as well:
   * inverse depth: ``2/A sum |1/(depth + 1e-6) - (s_g q + t_g)|`` over the pixels whose predicted inverse depth q exceeds 0.05, fused
@@ -92,6 +93,25 @@ def rigid_points_registration(x, y, weights):
     R = (U @ D @ Vt).to(x.device)
     s = (S * torch.diagonal(D)).sum().to(x.device) / (w * (xc * xc).sum(-1)).sum()
     return s.float(), R.float(), (ym - s * (R @ xm)).float()
+
+
+def estimate_focal_weiszfeld(rays, pp=None, iters=10):
+    """Focal of each map in `rays` [B, H, W, 3] (point map or ray-direction map) = argmin_f sum | pixel - f (x, y) / z |: closed-form L2
+    start, then `iters` rounds of least squares re-weighted by the inverse residual. What align_group uses to initialise the focals
+    from the ray maps (init_im_poses.py:133-136 -> estimate_focal :810-817 -> dust3r/post_process.py:12-60, focal_mode='weiszfeld',
+    without its optional clipping). Host-side initialisation math: a dozen reductions per clip, any device."""
+    B, H, W, _ = rays.shape
+    ys, xs = torch.meshgrid(torch.arange(H, device=rays.device), torch.arange(W, device=rays.device), indexing="ij")
+    pp = torch.tensor([W / 2, H / 2], device=rays.device).expand(B, 2) if pp is None else pp
+    px = torch.stack([xs, ys], -1).reshape(1, H * W, 2).float() - pp.reshape(B, 1, 2)
+    r = rays.reshape(B, H * W, 3).float()
+    q = (r[..., :2] / r[..., 2:3]).nan_to_num(posinf=0, neginf=0)
+    qp, qq = (q * px).sum(-1), q.square().sum(-1)
+    f = qp.mean(1) / qq.mean(1)
+    for _ in range(iters):
+        w = (px - f.view(B, 1, 1) * q).norm(dim=-1).clip(min=1e-8).reciprocal()
+        f = (w * qp).mean(1) / (w * qq).mean(1)
+    return f
 
 
 def lr_at(t, schedule, lr_base, lr_min):
@@ -419,9 +439,11 @@ class GroupAligner:
 
     # ---- initialisation (init_im_poses.py:82-181, 569-635) ----------------------------------------------------------------------
     @torch.no_grad()
-    def init_from_group(self, traj, focal=None):
+    def init_from_group(self, traj, focal=None, raymaps=None):
         """traj [G, S, 4, 4]: camera-to-world of every frame in its window's own frame (the Plücker cameras of N2);
-        focal: pixels (None: estimated from window 0's first point map)."""
+        focal: pixels; raymaps [G, S, H, W, 3] (pred_pts['raydir']): when given and `focal` is None, every image's focal is the
+        Weiszfeld estimate on its first ray map and the shared focal their mean, as align_group / init_from_pts3d_group do
+        (init_im_poses.py:133-136, 183-185, 627-628); with neither, the focal is estimated from window 0's first point map."""
         G, S, H, W = self.G, self.S, self.H, self.W
         pred = self.pred.reshape(G, S, H * W, 3)
         conf = self.conf.reshape(G, S, H * W)
@@ -450,6 +472,15 @@ class GroupAligner:
             self.P["pw_poses"][g, 4:7] = signed_log1p(T / s)
             self.P["pw_poses"][g, 7] = torch.log(s)
         sf = float((math.log(self.base_scale) - self.P["pw_poses"][:, -1].mean()).exp()) if self.norm_pw_scale else 1.0
+        if focal is None and raymaps is not None:
+            first = {}
+            for g, grp in enumerate(self.groups):
+                for k, i in enumerate(grp):
+                    first.setdefault(i, (g, k))
+            rm = raymaps.reshape(G, S, H, W, 3)
+            per_image = estimate_focal_weiszfeld(torch.stack([rm[g, k] for g, k in (first[i] for i in range(self.n))]).to(self.dev))
+            self.init_focals = per_image
+            focal = float(per_image.mean()) if self.shared_focal else per_image
         if focal is None:
             p0, ys, xs = pred[0, 0], *torch.meshgrid(torch.arange(H, device=self.dev), torch.arange(W, device=self.dev), indexing="ij")
             u, v = (xs.reshape(-1).float() - W / 2), (ys.reshape(-1).float() - H / 2)
@@ -458,7 +489,10 @@ class GroupAligner:
             fy = (v * p0[:, 2] / p0[:, 1])[ok & (v.abs() > H / 8)]
             cand = torch.cat([fx[torch.isfinite(fx)], fy[torch.isfinite(fy)]])
             focal = float(cand.median()) if cand.numel() else float(max(H, W))
-        self.P["im_focals"][:] = FOCAL_BREAK * math.log(focal)
+        if torch.is_tensor(focal):
+            self.P["im_focals"][:, 0] = FOCAL_BREAK * torch.log(focal)
+        else:
+            self.P["im_focals"][:] = FOCAL_BREAK * math.log(focal)
         sky = 0.0
         for i in range(self.n):
             M = im_poses[i].clone()

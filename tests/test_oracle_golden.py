@@ -330,3 +330,13 @@ def test_alignment_oracle_depth_and_trajectory_terms_vs_reference():
     for k in P:
         if d["grads_at_after"][k] is not None:
             assert rel(P[k].grad, d["grads_at_after"][k]) < 1e-4, (k, rel(P[k].grad, d["grads_at_after"][k]))
+
+
+def test_focal_initialisation_vs_reference_weiszfeld():
+    """geo4d_amd.align.estimate_focal_weiszfeld (host-side initialisation math, device-agnostic torch) against the reference's
+    estimate_focal_knowing_depth(focal_mode='weiszfeld') on three synthetic ray maps incl. rays with z = 0."""
+    from geo4d_amd.align import estimate_focal_weiszfeld
+    g = torch.load(os.path.join(G, "align_tiny.pt"), weights_only=False)["focal"]
+    f = estimate_focal_weiszfeld(g["rays"], g["pp"])
+    assert torch.allclose(f, g["weiszfeld"], rtol=1e-6, atol=0), (f, g["weiszfeld"])
+    assert torch.allclose(estimate_focal_weiszfeld(g["rays"]), g["weiszfeld"], rtol=1e-6, atol=0)     # default principal point = centre
