@@ -252,3 +252,24 @@ def test_loop_with_late_terms_vs_reference(fix, dev, graph):
         dev_ = (a.P[k].cpu() - ref).abs()
         print("   ", k, "median", float(dev_.median()), "max", float(dev_.max()))
         assert dev_.median() < 3e-3 and dev_.max() < 8e-2 and (dev_.numel() < 64 or (dev_ < 5e-3).float().mean() > 0.95), k
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_focal_initialisation_from_ray_maps(fix, dev, shared):
+    """init_from_group(raymaps=...): every image's focal = the reference's Weiszfeld estimate on its first ray map, the shared
+    focal their mean (init_im_poses.py:133-136, 627-628) - on the device, against the fixture values of dust3r.post_process."""
+    from geo4d_amd.align import GroupAligner, estimate_focal_weiszfeld
+    fo = fix["focal"]
+    assert torch.allclose(estimate_focal_weiszfeld(fo["rays"].to(dev), fo["pp"].to(dev)).cpu(), fo["weiszfeld"], rtol=2e-5)
+    groups = [[0, 1], [1, 2]]                                           # three images, two windows of two; ray maps of 24 x 32
+    H, W = fo["rays"].shape[1:3]
+    gen = torch.Generator().manual_seed(9)
+    pred = torch.randn((2, 2, H, W, 3), generator=gen) * 0.1 + torch.tensor([0.0, 0.0, 2.0])
+    conf = torch.ones(2, 2, H, W)
+    rm = torch.stack([fo["rays"][[0, 1]], fo["rays"][[1, 2]]])          # window 1 sees image 1 again: its first occurrence (window 0) counts
+    a = GroupAligner(groups, pred.to(dev), conf.to(dev), shared_focal=shared)
+    a.init_from_group(torch.eye(4).repeat(2, 2, 1, 1).to(dev), raymaps=rm.to(dev))
+    want = fo["weiszfeld"].mean().reshape(1) if shared else fo["weiszfeld"]
+    got = a.get_focals().cpu().flatten()[: want.numel()]
+    print("[align focal init]", got.tolist(), want.tolist())
+    assert torch.allclose(got, want, rtol=1e-4)

@@ -1,0 +1,5 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R || exit 1
+O=$R/gpurun_out/r2s; mkdir -p $O
+timeout 60 python -m pytest tests/test_align_gpu.py -m gpu -q -s -k "focal_init or late_terms_loss" > $O/tests.log 2>&1; echo "rc=$?"; grep -E "^\[align focal|passed|failed|^E " $O/tests.log | cut -c1-200 | tail -8
