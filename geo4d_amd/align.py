@@ -375,7 +375,8 @@ class GroupAligner:
         lrs = torch.tensor([lr_at(it / niter, schedule, lr, lr_min) for it in range(niter)], dtype=torch.float64)
         table = torch.stack([lrs, 1 - b1 ** steps, (1 - b2 ** steps).sqrt()], 1).float().to(self.dev)            # [niter, 3]
         has_late = self.invdepth is not None or self.traj is not None
-        start = min(self.start_iter, niter) if has_late else niter
+        # iteration at which the late terms (and their parameters' Adam moments) start; 0 when a previous call already started them
+        start = 0 if self.state is not None else (min(self.start_iter, niter) if has_late else niter)
         lsteps = (steps - start).clamp_min(1)                                  # a late parameter's own step count
         table_late = torch.stack([lrs, 1 - b1 ** lsteps, (1 - b2 ** lsteps).sqrt()], 1).float().to(self.dev)
         idx = torch.zeros((1,), dtype=torch.long, device=self.dev)
