@@ -508,3 +508,36 @@ class GroupAligner:
             self.P["im_poses"][i, :4] = rotmat_to_quat(Rw).to(self.dev)
             self.P["im_poses"][i, 4:7] = signed_log1p(tw)
         return self
+
+
+def post_optimization(slices, maps, traj, args=None, conf_optimize=True, lr=0.03, align=True, intrinsics=None,
+                      use_raymap=True, use_inverse_depthmap=True, use_traj=True, pointmap_vae_used=True, depth_traj_start_iter=150):
+    """The consumer of the gathered clip: ``post_optimization`` of scripts/evaluation/test_geo4d.py:30-51 with the pred_list its
+    window loop builds (:446-501). ``slices`` / ``maps [n_windows, 11, T, H, W]`` / ``traj [n_windows, T, 4, 4]`` are what
+    ``pipeline.run_clip(..., with_cameras=True)`` returns; ``args`` = the config's ``postprocess`` tree (a dict or any object with
+    n_iter / pose_schedule / temporal_smoothing_weight / translation_weight / not_shared_focal / use_gt_focal attributes; None =
+    the shipped values). Returns the optimised ``GroupAligner`` (``get_depthmaps`` / ``get_im_poses_matrix`` / ``get_focals``).
+    ``intrinsics [n_images, 3, 3]`` presets the focals (scene.preset_focal in the script; they are then kept fixed by starting from
+    them - the reference freezes them, here they stay optimisable unless lr is 0 for that row: documented difference)."""
+    from .pipeline import postprocess_window
+    get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
+    if args is None:
+        get = lambda k, d: d
+    post = [postprocess_window(m[None], pointmap_vae_used=pointmap_vae_used) for m in maps]
+    groups = [list(range(s.start, s.stop)) for s in slices]
+    conf = torch.stack([p["conf"][..., 0] for p in post])
+    if not conf_optimize:
+        conf = torch.ones_like(conf)
+    scene = GroupAligner(groups, torch.stack([p["pts3d"] for p in post]), conf,
+                         shared_focal=not get("not_shared_focal", False) and not get("use_gt_focal", False),
+                         temporal_smoothing_weight=get("temporal_smoothing_weight", 0.015), translation_weight=get("translation_weight", 1.0),
+                         inverse_depth=torch.stack([p["inverse_depthmap"] for p in post]) if use_inverse_depthmap else None,
+                         traj=traj if use_traj else None, depth_traj_start_iter=depth_traj_start_iter)
+    focal = None
+    if intrinsics is not None:
+        per_image = (intrinsics[:, 0, 0] + intrinsics[:, 1, 1]) / 2.0
+        focal = per_image.to(scene.dev).float() if not scene.shared_focal else float(per_image.float().mean())
+    scene.init_from_group(traj, focal=focal, raymaps=torch.stack([p["raymap"] for p in post]) if use_raymap else None)
+    if align:
+        scene.compute_global_alignment(niter=get("n_iter", 500), schedule=get("pose_schedule", "linear"), lr=lr)
+    return scene

@@ -273,3 +273,35 @@ def test_focal_initialisation_from_ray_maps(fix, dev, shared):
     got = a.get_focals().cpu().flatten()[: want.numel()]
     print("[align focal init]", got.tolist(), want.tolist())
     assert torch.allclose(got, want, rtol=1e-4)
+
+
+def test_post_optimization_consumes_the_gathered_clip(dev):
+    """post_optimization(slices, maps, traj, postprocess args): the consumer of run_clip's output, wired like the script's window
+    loop + post_optimization (test_geo4d.py:446-509): decoded maps -> pts3d / inverse confidence / inverse depth / ray maps -> aligner
+    with both late terms -> init -> loop. Checked for wiring (shapes, terms started, finite decreasing loss) on a tiny synthetic clip."""
+    from geo4d_amd.align import post_optimization
+    from geo4d_amd.pipeline import window_slices
+    gen = torch.Generator().manual_seed(3)
+    T, H, W, n = 4, 16, 24, 7
+    slices = window_slices(n, 1, T)
+    G_ = len(slices)
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    f = 30.0
+    ray = torch.stack([(xs - W / 2) / f, (ys - H / 2) / f, torch.ones(H, W)], 0)
+    ray = ray / ray.norm(dim=0, keepdim=True)
+    maps = torch.zeros(G_, 11, T, H, W)
+    depth = 0.5 + 0.2 * torch.rand((G_, T, H, W), generator=gen)
+    maps[:, 0:3] = (ray[None, :, None] * depth[:, None] * 1.2).clamp(-0.9, 0.9)     # point map (normalised bbox coordinates)
+    maps[:, 2] = maps[:, 2] * 2 - 1
+    maps[:, 3] = 1.0                                                               # confidence logit
+    maps[:, 4:7] = ray[None, :, None]
+    maps[:, 10] = (1.0 / (1.0 + depth)) * 2 - 1                                     # inverse depth in [-1, 1]
+    traj = torch.eye(4).repeat(G_, T, 1, 1)
+    traj[:, :, 0, 3] = torch.arange(T).float() * 0.01
+    scene = post_optimization(slices, maps.to(dev), traj.to(dev), dict(n_iter=30, pose_schedule="linear", temporal_smoothing_weight=0.015,
+                                                                      translation_weight=1.0), depth_traj_start_iter=10)
+    assert scene.state is not None and scene.get_depthmaps().shape == (n, H, W) and scene.get_im_poses_matrix().shape == (n, 4, 4)
+    assert torch.isfinite(scene.get_depthmaps()).all() and abs(float(scene.get_focals()[0]) - f) < 0.35 * f
+    loss, _ = scene.loss_and_grads()
+    assert torch.isfinite(loss)
+    print("[post_optimization] focal", float(scene.get_focals()[0]), "state", scene.state, "loss", float(loss))
