@@ -166,6 +166,7 @@ class GroupAligner:
         self.traj = None if traj is None else traj.reshape(G, S, 4, 4).float().to(self.dev)
         self.start_iter = depth_traj_start_iter
         self.state = None                        # after the start iteration: dict(invalid_depth_groups, valid_traj_groups)
+        self.frozen = set()                      # parameter names Adam leaves alone (preset_focal(..., requires_grad=False) -> {"im_focals"})
         self.slot_img = torch.tensor(e_all, dtype=torch.int32, device=self.dev)
         self.e_all = torch.tensor(e_all, dtype=torch.long, device=self.dev)
         if self.invdepth is not None:
@@ -394,6 +395,8 @@ class GroupAligner:
                                                     hyper.data_ptr(), b1, b2, eps, ops._stream()), "geo4d_adam_step_dev")
             late = self._late_keys()
             for k in ("im_poses", "im_focals", "pw_poses") + late:   # a few dozen numbers each: plain tensor ops, same formula
+                if k in self.frozen:
+                    continue
                 g, (m, v), h = grads[k], mom[k], hyper_late if k in late else hyper
                 m.mul_(b1).add_(g, alpha=1 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1 - b2)
@@ -517,8 +520,7 @@ def post_optimization(slices, maps, traj, args=None, conf_optimize=True, lr=0.03
     ``pipeline.run_clip(..., with_cameras=True)`` returns; ``args`` = the config's ``postprocess`` tree (a dict or any object with
     n_iter / pose_schedule / temporal_smoothing_weight / translation_weight / not_shared_focal / use_gt_focal attributes; None =
     the shipped values). Returns the optimised ``GroupAligner`` (``get_depthmaps`` / ``get_im_poses_matrix`` / ``get_focals``).
-    ``intrinsics [n_images, 3, 3]`` presets the focals (scene.preset_focal in the script; they are then kept fixed by starting from
-    them - the reference freezes them, here they stay optimisable unless lr is 0 for that row: documented difference)."""
+    ``intrinsics [n_images, 3, 3]`` presets the focals and freezes them (scene.preset_focal(..., requires_grad=False) in the script)."""
     from .pipeline import postprocess_window
     get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
     if args is None:
@@ -538,6 +540,8 @@ def post_optimization(slices, maps, traj, args=None, conf_optimize=True, lr=0.03
         per_image = (intrinsics[:, 0, 0] + intrinsics[:, 1, 1]) / 2.0
         focal = per_image.to(scene.dev).float() if not scene.shared_focal else float(per_image.float().mean())
     scene.init_from_group(traj, focal=focal, raymaps=torch.stack([p["raymap"] for p in post]) if use_raymap else None)
+    if intrinsics is not None:
+        scene.frozen.add("im_focals")
     if align:
         scene.compute_global_alignment(niter=get("n_iter", 500), schedule=get("pose_schedule", "linear"), lr=lr)
     return scene

@@ -305,3 +305,11 @@ def test_post_optimization_consumes_the_gathered_clip(dev):
     loss, _ = scene.loss_and_grads()
     assert torch.isfinite(loss)
     print("[post_optimization] focal", float(scene.get_focals()[0]), "state", scene.state, "loss", float(loss))
+    # a second call continues with the late terms on (their Adam steps count from this call's first iteration)
+    final2, hist2 = scene.compute_global_alignment(niter=5, lr=0.003, schedule="linear", history=True)
+    assert all(map(lambda x: x == x and x < 10, hist2)) and len(hist2) == 5
+    # known intrinsics: preset and frozen (scene.preset_focal(..., requires_grad=False), test_geo4d.py:44-45)
+    K = torch.eye(3).repeat(n, 1, 1)
+    K[:, 0, 0], K[:, 1, 1] = 41.0, 43.0
+    fixed = post_optimization(slices, maps.to(dev), traj.to(dev), dict(n_iter=12, pose_schedule="linear"), intrinsics=K, depth_traj_start_iter=6)
+    assert abs(float(fixed.get_focals()[0]) - 42.0) < 1e-3, float(fixed.get_focals()[0])

@@ -2,4 +2,4 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R || exit 1
 O=$R/gpurun_out/r2s; mkdir -p $O
-timeout 60 python -m pytest tests/test_align_gpu.py -m gpu -q -s -k "post_optimization or focal_init" > $O/tests.log 2>&1; echo "rc=$?"; grep -E "^\[align focal|^\[post_opt|passed|failed|^E " $O/tests.log | cut -c1-200 | tail -8
+timeout 60 python -m pytest tests/test_align_gpu.py -m gpu -q -s > $O/tests.log 2>&1; echo "rc=$?"; grep -E "^\[align focal|^\[post_opt|passed|failed|^E " $O/tests.log | cut -c1-200 | tail -8
