@@ -133,11 +133,13 @@ def cpu_baseline(model, pvae, ddim_steps, T, h, w, budget_s=240):
         res, scale = run(8, 8, 120), (h * w) / 64.0
         note = f"the real-size sample did not finish within {budget_s} s on this host: 8x8 latents scaled x{scale:.0f} by token count"
     if res is None:
-        return {"value": None, "unit": "denoised latent frames/s", "cores": cores, "kind": "port", "sample": "oracle did not finish on this host"}
+        return {"value": None, "unit": "denoised latent frames/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+                "sample": "oracle did not finish on this host"}
     t_unet, t_dec = res[0] * scale, res[1] * scale
     t_window = ddim_steps * t_unet + T * 4 * t_dec
-    return {"value": T / t_window, "unit": "denoised latent frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 on {cores} threads ({note}): 1 timed U-Net forward at 1x20x{T}x{h}x{w} ({t_unet:.1f} s) + 1 timed "
+    return {"value": T / t_window, "unit": "denoised latent frames/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle fp32 on {cores} of the host's {os.cpu_count()} logical cores (threads capped at 32: more make these small fp32 "
+                      f"convs / einsums slower) ({note}): 1 timed U-Net forward at 1x20x{T}x{h}x{w} ({t_unet:.1f} s) + 1 timed "
                       f"conf-decode frame at 1x4x{h}x{w} -> {8 * h}x{8 * w} ({t_dec:.1f} s), after a small warm-up forward; window = "
                       f"{ddim_steps} forwards + {4 * T} frame decodes = {t_window:.0f} s (the 3 plain decodes are counted at the conf-decode "
                       "cost: <= 3 % high)"}
@@ -157,6 +159,57 @@ def gemm_timeline(model, x_T, cond, fs, dev):
     return len(tl), sum(f for f, _, _ in tl) / 1e12, sum(a.elapsed_time(b) for _, a, b in tl)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """Re-run this command line as `n` ranks: python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1
+    --master-port <free> bench.py <same flags>. Returns the launcher's exit code. HSA_ENABLE_IPC_MODE_LEGACY=0 is kept / set: the
+    host driver only supports dmabuf IPC, RCCL needs it across processes."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world, local):
+    """`--launch-check`: the rendezvous, the device binding and the timing protocol of the real run (barrier + synchronize on both
+    sides, MAX over ranks) around an EMPTY step. No kernels, so it also runs where there is no GPU (gloo) - that is the CPU test
+    of the `python bench.py --gpus N` entry."""
+    import torch.distributed as dist
+    cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if cuda else torch.device("cpu")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0, float(rank)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank_seen": int(tt[1].item()), "barrier_ms": 1e3 * tt[0].item(),
+                          "backend": dist.get_backend() if world > 1 else None, "device": str(dev),
+                          "config": {"parallelism": f"window-dp{world}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,13 +223,22 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="clips per GPU per step (BASELINE configs[4]: 4)")
     ap.add_argument("--decode", default=None, choices=["local", "sharded"], help="N > 1: decode every rank's own window locally, or "
                     "frame-shard the round's decode over all ranks (default)")
+    ap.add_argument("--launch-check", action="store_true", help="no compute: bring the N-rank job up (RCCL on GPUs, gloo without), run "
+                    "the barrier / max-over-ranks timing protocol on an empty step and print the JSON skeleton (tests/test_dist_cpu.py)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the plain-bf16 timing reported next to the bf16x3 headline")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (the driver's command form): re-launch this very command line as N ranks, one per
+        # GPU, under torch.distributed.run on the loopback interface; rank 0 of that job prints the JSON line
+        raise SystemExit(self_launch(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:            # checked BEFORE the rendezvous: a wrong count would hang in it
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} (the launcher's --nproc-per-node must equal --gpus)")
     rank, world, local = gdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.launch_check:
+        return launch_check(args, rank, world, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local)
@@ -285,6 +347,9 @@ def main():
                                         "f32": "exact f32 MFMA"}[args.dtype],
                        "parallelism": f"window-dp{world}" + (f" + {'frame-sharded' if decode_mode == 'sharded' else 'local'} VAE decode + "
                                                              "RCCL all-gather of decoded maps (async, overlapped with the next denoise)" if world > 1 else ""),
+                       "ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                       "collective_backend": (torch.distributed.get_backend() + " (RCCL over xGMI)" if torch.distributed.get_backend() == "nccl"
+                                              else torch.distributed.get_backend()) if world > 1 else None,
                        "hipgraph": not args.no_graph},
             "split_ms_per_step": {"ddim_denoise": split[0] / args.steps, "vae_decode_4_modalities": split[1] / args.steps},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (MFMA implicit GEMM: every conv / linear / batched GEMM of the path)",

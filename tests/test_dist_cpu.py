@@ -114,3 +114,25 @@ def test_shard_tables():
     assert [len(shard_windows(30, r, 8)) for r in range(8)] == [4, 4, 4, 4, 4, 4, 3, 3]
     assert window_owner_table(14, 8) == ([2, 2, 2, 2, 2, 2, 1, 1], 2)
     assert sorted(sum((shard_windows(14, r, 8) for r in range(8)), [])) == list(range(14))
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command form) must bring up 2 ranks by itself;
+    --launch-check runs the rendezvous + barrier / max-over-ranks protocol without kernels, so it works on the gloo CPU rig."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # ONE JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["max_rank_seen"] == 1 and rec["config"]["parallelism"] == "window-dp2"
+    # a launcher whose rank count disagrees with --gpus is refused with a message, not an assert
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True,
+                        text=True, timeout=120)
+    assert r2.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in (r2.stdout + r2.stderr)
