@@ -82,6 +82,7 @@ class LatentDiffusion(nn.Module):
         if use_dynamic_rescale:
             arr = np.concatenate((np.linspace(1.0, base_scale, turning_step), np.full(self.num_timesteps, base_scale)))
             self.register_buffer("scale_arr", f32(arr))
+        self.register_load_state_dict_post_hook(lambda mod, inc: mod._after_load(inc))
 
     @property
     def device(self):
@@ -138,9 +139,16 @@ class LatentDiffusion(nn.Module):
 
     def __getattr__(self, name):
         if name in LatentDiffusion._FRONTEND and "_modules" in self.__dict__ and name not in self._modules:
-            self.build_frontend(only=name)
+            try:
+                self.build_frontend(only=name)
+            except NotImplementedError as e:          # hasattr(model, "embedder") must answer False, not throw
+                raise AttributeError(f"{type(self).__name__}.{name}: {e}") from None
             return self._modules[name]
         return super().__getattr__(name)
+
+    def _frontend_configured(self, name):
+        cfg = getattr(self, LatentDiffusion._FRONTEND[name], None)
+        return isinstance(cfg, dict) and str(cfg.get("target", "")).startswith("geo4d_amd.")
 
     def build_frontend(self, only=None):
         """Instantiate ``cond_stage_model`` (text), ``embedder`` (image) and ``image_proj_model`` (Resampler) from their yaml
@@ -155,11 +163,36 @@ class LatentDiffusion(nn.Module):
                                           "or point the yaml section at geo4d_amd.encoders.*")
             cfg = {"target": cfg["target"], "params": dict(cfg.get("params") or {}, compute_dtype=getattr(unet, "compute_dtype", None))}
             self._modules[name] = instantiate_from_config(cfg).to(self.device)     # (add_module would probe hasattr -> __getattr__ -> here)
+            # a lazily built encoder holds its constructor's random weights until a state_dict that carries its tensors is loaded:
+            # remembered, and said out loud when a context is computed from it (context_for / get_learned_conditioning)
+            self.__dict__.setdefault("_frontend_unloaded", set()).add(name)
+            self.__dict__.pop("_geo4d_context_cache", None)
         return self
+
+    def _warn_unloaded(self, *names):
+        bad = sorted(n for n in names if n in self.__dict__.get("_frontend_unloaded", ()))
+        if bad:
+            import warnings
+            warnings.warn(f"geo4d_amd: {', '.join(bad)} built lazily and NO checkpoint weights loaded into it since: the cross-attention "
+                          "context comes from randomly initialised encoders (call build_frontend() before load_state_dict, or use "
+                          "load_reference_state_dict, which does)", RuntimeWarning, stacklevel=3)
+
+    def _after_load(self, incompatible=None):
+        """Bookkeeping after ANY load_state_dict: encoders whose tensors were all present count as loaded; cached contexts computed
+        from the old weights are dropped (pipeline.image_guided_synthesis caches the step-constant context per model)."""
+        missing = set(getattr(incompatible, "missing_keys", ()) or ())
+        un = self.__dict__.setdefault("_frontend_unloaded", set())
+        for name in list(un):
+            mod = self._modules.get(name)
+            if mod is not None and not any(k.startswith(name + ".") for k in missing):
+                un.discard(name)
+        self.__dict__.pop("_geo4d_context_cache", None)
 
     def get_learned_conditioning(self, c):
         """ddpm3d.py:640-651: prompts (or token ids) -> text context [B, 77, 1024]."""
-        return self.cond_stage_model.encode(c)
+        enc = self.cond_stage_model
+        self._warn_unloaded("cond_stage_model")
+        return enc.encode(c)
 
     def get_first_stage_encoding(self, encoder_posterior, noise=None):
         """ddpm3d.py:674-681: sample the posterior (or pass a tensor through) and apply scale_factor."""
@@ -203,6 +236,8 @@ class LatentDiffusion(nn.Module):
         """The cross-attention context of test_geo4d.py:118-158 for modality 'pc_ray_cross_depth': text tokens (77) followed by
         the Resampler's image tokens (16 per frame). ``cross_attention`` False (the shipped setting): ONE zero image per sample ->
         [B, 77 + 16*T, 1024]; True: every frame of ``frames`` [b, c, t, h, w] is embedded."""
+        self.embedder, self.image_proj_model             # build both before the check below
+        self._warn_unloaded("embedder", "image_proj_model")
         if self.cross_attention:
             b, c, t, h, w = frames.shape
             emb = self.embedder(frames.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w))
@@ -214,13 +249,19 @@ class LatentDiffusion(nn.Module):
     # ---- checkpoints (test_geo4d.py:54-81): reference keys model.diffusion_model.* / first_stage_model.* ---------
     def load_reference_state_dict(self, state_dict):
         sd = state_dict.get("state_dict", state_dict)
+        # the conditioning encoders are built lazily: a checkpoint that carries their tensors gets them built FIRST (when the yaml
+        # points those sections at geo4d_amd.encoders.*), so its cond_stage_model.* / embedder.* / image_proj_model.* tensors are
+        # loaded instead of being reported as skipped and replaced by random weights at first use
+        for name in LatentDiffusion._FRONTEND:
+            if name not in self._modules and self._frontend_configured(name) and any(k.startswith(name + ".") for k in sd):
+                self.build_frontend(only=name)
         own = self.state_dict()
         picked = {k: v for k, v in sd.items() if k in own}
         missing = [k for k in own if k not in picked]
         if missing:
             raise KeyError(f"checkpoint lacks {len(missing)} tensors of the hot path, e.g. {missing[:3]}")
         skipped = sorted({k.split(".")[0] for k in sd if k not in own})
-        self.load_state_dict(picked, strict=True)
+        self.load_state_dict(picked, strict=True)     # (the post hook marks the encoders loaded and drops cached contexts)
         return skipped   # e.g. ['cond_stage_model', 'embedder', 'image_proj_model']: N3 components
 
 

@@ -12,9 +12,12 @@ wide — per-head batched conv_gemm QK^T / PV around a (causal) row-softmax kern
 GEMM's K granularity at pack time. The architecture constants default to ViT-H-14 (open_clip model config: text width 1024 /
 24 layers / 16 heads / vocab 49408 / context 77; vision width 1280 / 32 layers / 16 heads / patch 14 / image 224).
 
-Tokenisation: open_clip's BPE vocabulary file is not part of the reference repository; ``FrozenOpenCLIPEmbedder`` therefore takes
-token ids, a user-supplied ``tokenizer`` callable, or the empty prompt ``""`` (= <start> <end> padding: the only prompt the
-shipped inference uses, test_geo4d.py:124-126).
+Tokenisation (geo4d_amd/tokenizer.py): the CLIP byte-pair encoder of ``open_clip.tokenize`` (condition.py:207-210) restated; its merge
+table ``bpe_simple_vocab_16e6.txt.gz`` ships in the open_clip wheel, not in the reference repository, so it is loaded from a
+user-supplied path (``bpe_path=`` / ``GEO4D_CLIP_BPE``). ``FrozenOpenCLIPEmbedder`` takes prompts (tokenised with that table),
+int64 token ids, or a ``tokenizer`` callable. The shipped scripts run with ``--text_input`` (scripts/infer_geo4d.sh:24), i.e. they
+encode the fixed prompt of test_geo4d.py:410; without ``--text_input`` the prompt is blanked to ``""`` (test_geo4d.py:124-126), which
+is <start> <end> + padding and needs no table.
 """
 import math
 
@@ -112,18 +115,19 @@ def _vit_block(e, x, B, N, heads, prec, causal):
 
 
 class FrozenOpenCLIPEmbedder(_Packed):
-    """Text tower (condition.py:174-234). ``forward(text)``: list of prompts (only "" without a tokenizer) or int64 token ids
-    [B, 77] -> [B, 77, width]."""
+    """Text tower (condition.py:174-234). ``forward(text)``: list of prompts (tokenised by geo4d_amd.tokenizer with the merge
+    table at ``bpe_path`` / $GEO4D_CLIP_BPE; "" needs none) or int64 token ids [B, 77] -> [B, 77, width]."""
     LAYERS = ["last", "penultimate"]
 
     def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", device="cuda", max_length=77, freeze=True, layer="last",
-                 width=1024, layers=24, heads=16, vocab_size=49408, tokenizer=None, compute_dtype=None):
+                 width=1024, layers=24, heads=16, vocab_size=49408, tokenizer=None, bpe_path=None, compute_dtype=None):
         super().__init__()
         assert layer in self.LAYERS
         if arch != "ViT-H-14":
             raise NotImplementedError("only the ViT-H-14 text tower of configs/inference_geo4d.yaml is described here")
         self.max_length, self.layer, self.layer_idx = max_length, layer, (1 if layer == "penultimate" else 0)
         self.width, self.layers, self.heads, self.vocab_size, self.tokenizer = width, layers, heads, vocab_size, tokenizer
+        self.bpe_path = bpe_path
         add = self.insert
         add("model.token_embedding.weight", (vocab_size, width)); add("model.positional_embedding", (max_length, width))
         for i in range(layers):
@@ -136,12 +140,17 @@ class FrozenOpenCLIPEmbedder(_Packed):
     def tokenize(self, text):
         if self.tokenizer is not None:
             return torch.as_tensor(self.tokenizer(text), dtype=torch.long)
-        toks = torch.zeros((len(text), self.max_length), dtype=torch.long)
-        for i, t in enumerate(text):
-            if t != "":
-                raise NotImplementedError("open_clip's BPE vocabulary is not available offline: pass token ids, construct with "
-                                          "tokenizer=callable, or use the empty prompt the shipped inference uses")
-            toks[i, 0], toks[i, 1] = SOT, EOT
+        if isinstance(text, str):
+            text = [text]
+        if all(t == "" for t in text):                       # <start> <end> padding: no merge table needed
+            toks = torch.zeros((len(text), self.max_length), dtype=torch.long)
+            toks[:, 0], toks[:, 1] = SOT, EOT
+            return toks
+        from .tokenizer import SimpleTokenizer
+        self.tokenizer = SimpleTokenizer(self.bpe_path, context_length=self.max_length)   # FileNotFoundError names what to supply
+        toks = self.tokenizer(text)
+        if int(toks.max()) >= self.vocab_size:
+            raise ValueError(f"token id {int(toks.max())} outside the embedding table ({self.vocab_size} rows): wrong merge table?")
         return toks
 
     @torch.no_grad()

@@ -125,7 +125,9 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
         # model.cross_attention (then every frame). Built lazily from geo4d_amd.encoders and cached: constant across windows.
         if not text_input:
             prompts = [""] * batch_size
-        key = (tuple(prompts), bool(model.cross_attention), tuple(videos.shape) if model.cross_attention else tuple(videos.shape[-2:]))
+        # keyed on the compute mode too; the cache is dropped by LatentDiffusion._after_load / build_frontend (weights changed)
+        key = (tuple(prompts), bool(model.cross_attention), tuple(videos.shape) if model.cross_attention else tuple(videos.shape[-2:]),
+               getattr(model.model.diffusion_model, "compute_dtype", None))
         cache = model.__dict__.setdefault("_geo4d_context_cache", {})
         ctx = cache.get(key) if not model.cross_attention else None
         if ctx is None:

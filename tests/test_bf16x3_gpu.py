@@ -146,7 +146,7 @@ def _sdpa(q, k, v, scale):
 
 
 @pytest.mark.parametrize("variant", [1, 3])
-@pytest.mark.parametrize("N", [40, 200, 640, 2304])
+@pytest.mark.parametrize("N", [40, 200, 640, 2304, 9216])   # 2304 / 9216: BASELINE configs[2] / [4] tokens per frame
 def test_attention_self(dev, N, variant):
     from geo4d_amd import ops
     B, H = (3, 5) if N < 600 else (2, 2)

@@ -228,3 +228,52 @@ def test_library_path_override_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
     monkeypatch.undo()
     assert _lib.load() is not None
+
+
+def _tiny_lvd(frontend=True):
+    from geo4d_amd.diffusion import LatentVisualDiffusion
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "unet_tiny.pt"), weights_only=False)
+    v = torch.load(os.path.join(ROOT, "tests", "golden", "vae_tiny.pt"), weights_only=False)
+    fe = dict(cond_stage_config={"target": "geo4d_amd.encoders.FrozenOpenCLIPEmbedder", "params": dict(layer="penultimate", width=64, layers=2, heads=1, vocab_size=600)},
+              img_cond_stage_config={"target": "geo4d_amd.encoders.FrozenOpenCLIPImageEmbedderV2", "params": dict(width=64, layers=1, heads=1, image_size=28, patch_size=14, embed_dim=32)},
+              image_proj_stage_config={"target": "geo4d_amd.encoders.Resampler", "params": dict(dim=64, depth=1, dim_head=64, heads=1, num_queries=2, embedding_dim=64, output_dim=128, video_length=4)})
+    if not frontend:
+        fe = dict(cond_stage_config={"target": "lvdm.modules.encoders.condition.FrozenOpenCLIPEmbedder", "params": {}})
+    return LatentVisualDiffusion(unet_config={"target": "geo4d_amd.unet.UNetModel", "params": dict(g["unet_config"])},
+                                 first_stage_config={"target": "geo4d_amd.vae.AutoencoderKL", "params": dict(ddconfig=v["ddconfig"], lossconfig=None, embed_dim=4, adaptorconfig=v["adaptorconfig"])},
+                                 parameterization="v", conditioning_key="hybrid", rescale_betas_zero_snr=True, linear_start=0.00085, linear_end=0.012,
+                                 use_dynamic_rescale=True, base_scale=0.7, scale_factor=0.18215, perframe_ae=True, modality="pc_ray_cross_depth", channels=16, **fe)
+
+
+def test_reference_checkpoint_loads_the_lazily_built_encoders():
+    """instantiate -> load checkpoint -> synthesize must not run on randomly initialised encoders. A checkpoint
+    that carries cond_stage_model.* / embedder.* / image_proj_model.* builds those modules before loading; encoders built lazily
+    AFTER a load are flagged and warned about; hasattr() on an unconfigured front-end answers False instead of throwing."""
+    import warnings
+    donor = _tiny_lvd().build_frontend()
+    for p in donor.parameters():
+        torch.nn.init.normal_(p, std=0.5)
+    ckpt = {"state_dict": {k: v.clone() for k, v in donor.state_dict().items()}}
+    fresh = _tiny_lvd()
+    assert "cond_stage_model" not in fresh._modules                            # still lazy
+    skipped = fresh.load_reference_state_dict(ckpt)
+    assert skipped == [] and all(n in fresh._modules for n in ("cond_stage_model", "embedder", "image_proj_model"))
+    for k, v in fresh.state_dict().items():
+        assert torch.equal(v, ckpt["state_dict"][k]), k
+    assert not fresh.__dict__.get("_frontend_unloaded")
+    # a hot-path-only checkpoint: the encoders stay lazy, and using them later warns that their weights are random
+    hot = {k: v for k, v in ckpt["state_dict"].items() if k.split(".")[0] in ("model", "first_stage_model") or "." not in k}
+    late = _tiny_lvd()
+    late.load_reference_state_dict(hot)
+    late.__dict__["_geo4d_context_cache"] = {"stale": 1}
+    late.build_frontend(only="cond_stage_model")
+    assert "cond_stage_model" in late.__dict__["_frontend_unloaded"] and "_geo4d_context_cache" not in late.__dict__
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        late._warn_unloaded("cond_stage_model")
+    assert any("randomly initialised" in str(x.message) for x in w)
+    late.__dict__["_geo4d_context_cache"] = {"stale": 1}
+    late.load_state_dict(ckpt["state_dict"], strict=False)                    # any later load marks them loaded + drops cached contexts
+    assert "cond_stage_model" not in late.__dict__["_frontend_unloaded"] and "_geo4d_context_cache" not in late.__dict__
+    foreign = _tiny_lvd(frontend=False)
+    assert not hasattr(foreign, "cond_stage_model") and not hasattr(foreign, "embedder")

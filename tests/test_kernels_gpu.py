@@ -225,8 +225,6 @@ def _vt(v, b, n, pad=None):
 @pytest.mark.parametrize("N", [40, 160, 200, 640, 2560, 2304, 9216])   # 2304 / 9216 = tokens per frame at 576x256 / 576x1024 (BASELINE configs[2], [4])
 def test_attention_self(dev, dtype, N):
     from geo4d_amd import ops
-    if N == 9216 and dtype == torch.float32:
-        pytest.skip("N = 9216 is exercised in bf16 / f16 (BASELINE configs[4] is an fp16 configuration)")
     B, H = (3, 5) if N < 600 else ((16, 10) if N == 640 else (1, 2))
     C_ = H * 64
     qkv = rnd((B * N, 3 * C_), dev, dtype, 30)
