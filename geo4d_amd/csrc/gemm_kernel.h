@@ -2,6 +2,7 @@
 // Included by gemm.hip (C ABI + validation) and by gemm_{bf16,f16,f32}.hip, each of which instantiates launch_typed<T>
 // for ONE element type so the three sets of kernels compile in parallel.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "geo4d_hip.h"
 
@@ -587,6 +588,10 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     return GEO4D_OK;
 }
 
+}  // namespace geo4d_gemm
+#include "gemm_kernel_v2.h"   // tile hints 21..29: 16x16x32 MFMA, register epilogue, persistent workgroups
+namespace geo4d_gemm {
+
 // Tile choice: score = MFMA efficiency of the tile shape x useful fraction x how full the last wave of
 // workgroups is (2 workgroups fit per CU by LDS => 512 slots on 256 CUs). Split-K multiplies the workgroup count
 // when M x N alone cannot fill the chip and K is deep enough to amortise the extra fp32 slab traffic.
@@ -595,6 +600,7 @@ struct TileCfg { int bm, bn; float eff; };
 template <typename T>
 int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     static constexpr TileCfg cfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.80f}, {64, 64, 0.62f}, {128, 32, 0.50f}};
+    if (p.tile_hint >= 21) return launch_v2_typed<T>(p, stream);
     if (p.tile_hint >= 11) {
         // explicit big-tile / deep-ring configurations, chosen by the host tuning table only. What they trade:
         // a CU can hold at most ~128 KB of LDS-DMA destinations, and a stage lands ~1 us after it is issued, so the

@@ -1,0 +1,443 @@
+// geo4d_amd/csrc/gemm_kernel_v2.h — second-generation implicit-GEMM kernel (round 3). Included by gemm_kernel.h; same ABI struct,
+// same gather / LDS-DMA ring / K order as conv_gemm_kernel, with the three changes the round-2 probes justified
+// (profiles/r02_mfma_probe_and_kloop.md, tools/probe/NEXT_KERNEL_NOTES.md):
+//   1. v_mfma_f32_16x16x32_{bf16,f16}: 86-87 % of the dense peak on random data where the 32x32x16 form keeps 76 %. Wave tiles are
+//      multiples of 16 rows / columns (80x80 becomes possible: 160x320 and 160x160 tiles on 8 / 4 waves, balanced over the 4 SIMDs,
+//      instead of the 10- / 5-wave layouts of tile hints 16 / 17).
+//      bf16x3 gets its own source-side LDS swizzle (xor key p ^ ((p>>2 ^ p>>1) & 1) << 1 on the row pair p): with the 16-row
+//      fragment a lane quarter reads chunk pair (2c, 2c+1), for which the 32x32 key is 2-way conflicted.
+//   2. register epilogue: with swapped operands a lane of the 16x16 accumulator owns 4 CONSECUTIVE output columns of one row, so
+//      bias / row-bias / activation / residual / rounding happen in registers and the stores are 16-byte (f32) or 8-byte (16-bit)
+//      vectors straight to global memory - no LDS transpose, hence the ring is free while the epilogue runs, hence
+//   3. persistent workgroups: grid = resident workgroups, a static round-robin tile loop; the NEXT tile's gather table, weight-row
+//      pointers and first K slab (LDS-DMA) are issued BEFORE the current tile's epilogue, so the DMA latency and the table's
+//      integer divides run under the epilogue's global traffic instead of in front of the next tile's first MFMA.
+// Not covered here (the host keeps such launches on conv_gemm_kernel): f32 element type, NCTHW outputs, gn_colsum.
+#pragma once
+
+namespace geo4d_gemm {
+
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma16<bf16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<f16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+// acc += a.b with a = ah + al, b = bh + bl (al.bl dropped): three dense bf16 MFMAs of the 16x16x32 form
+__device__ __forceinline__ void mma16_x3(f32x4& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+}
+
+// LDS slot of logical 16-byte chunk c in panel row r = c ^ swz_key<T>(r). ds_read_b128 is served in lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with lane = 16 * quarter + row, a group holds rows {0-3,12-15} of one quarter and
+// rows {4-11} of the next. 16-bit types read chunk 4h + quarter -> the plain row-pair key keeps the 16 slots distinct; bf16x3 reads
+// chunk 2 * quarter (+1), and needs rows {4-11} keyed with bit 1 flipped.
+template <typename T> __device__ __forceinline__ int swz_key(int row) {
+    const int p = (row >> 1) & 7;
+    if constexpr (IsX3<T>::value) return p ^ ((((p >> 2) ^ (p >> 1)) & 1) << 1);
+    else return p;
+}
+
+template <int BM, int BN>
+constexpr int v2_smem_bytes() { return 2 * (BM + BN) * PITCH + BM * MAXTAP * 4; }
+
+template <typename T, int BM, int BN, int WM, int WN, bool HOT>
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_conv_gemm_t p, const int splits, const int tiles_mn) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = BKC * EPC;
+    constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
+    constexpr int MB = WTM / 16, NB = WTN / 16;       // 16x16 accumulator blocks per wave
+    constexpr int RSTEP = NT / 8;                     // panel rows covered by one staging pass of the workgroup
+    constexpr int ACH = (BM + RSTEP - 1) / RSTEP, BCH = (BN + RSTEP - 1) / RSTEP;
+    constexpr int RING = 2 * (BM + BN) * PITCH;
+    static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && BM % 8 == 0 && BN % 8 == 0, "wave tiles are multiples of 16");
+    static_assert(!std::is_same<T, float>::value, "v2 serves the 16-bit MFMA forms (bf16, f16, bf16x3)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* rowpix = (int*)(smem + RING);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wr = wave / WN, wc = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int ntap = p.KT * p.KH * p.KW;
+    const int hw = p.Hout * p.Wout;
+    const long total = (long)tiles_mn * p.batch * splits;
+    const long G = gridDim.x;
+    const bool direct_rows = ntap == 1 && p.stride == 1 && p.ups == 1 && p.ph == 0 && p.pw == 0 && p.pt == 0 && p.Hin * p.Win == hw;
+    const int nslab_all = p.K / BK;
+    const int per = (nslab_all + splits - 1) / splits;
+    const T* __restrict__ Z = (const T*)p.zeros;
+    const int ccol = tid & 7;
+    const int r0 = tid >> 3;
+
+    // ---- state of the tile being staged (the NEXT tile while the current one is in its epilogue) ---------------------------------
+    int tm = 0, tn = 0, kz = 0, nslab = 0, tap = 0, c0 = 0;
+    long bz = 0;
+    const T* __restrict__ A = nullptr;
+    int pix[ACH];
+    const T* wptr[BCH];
+    int cA[ACH], cB[BCH];                              // source-side swizzle: LDS slot `ccol` of panel row r holds chunk ccol ^ key(r)
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) cA[i] = (ccol ^ swz_key<T>(r0 + i * RSTEP)) * EPC;
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) cB[i] = (ccol ^ swz_key<T>(r0 + i * RSTEP)) * EPC;
+
+    auto fetch_pix = [&]() {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int row = r0 + i * RSTEP;
+            if (direct_rows) {
+                const int m = tm * BM + row;
+                pix[i] = (row < BM && m < p.M) ? m : -1;
+            } else {
+                pix[i] = row < BM ? rowpix[row * ntap + tap] : -1;
+            }
+        }
+    };
+    auto setup_tile = [&](long w) {
+        const long t = w % tiles_mn, rest = w / tiles_mn;
+        bz = rest % p.batch;
+        kz = (int)(rest / p.batch);
+        tm = (int)(t / tiles_n);
+        tn = (int)(t - (long)tm * tiles_n);
+        A = (const T*)p.A + bz * p.a_bs;
+        const T* __restrict__ W = (const T*)p.W + bz * p.w_bs;
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int row = r0 + i * RSTEP, n = tn * BN + row;
+            wptr[i] = (row < BN && n < p.N) ? W + (long)n * p.ldw + cB[i] : nullptr;
+        }
+        const int s_begin = kz * per;
+        nslab = min(nslab_all, s_begin + per) - s_begin;
+        if (!direct_rows) {
+            // gather table: source pixel of (tile row, tap), -1 = zero padding. The previous tile's table is dead here: its last
+            // fetch_pix ran before the K loop's final barrier.
+            const int hlim = p.ups == 2 ? 2 * p.Hin : p.Hin, wlim = p.ups == 2 ? 2 * p.Win : p.Win;
+            const int ush = p.ups == 2 ? 1 : 0;
+            for (int e = tid; e < BM * ntap; e += NT) {
+                const int row = e / ntap, tp = e - row * ntap;
+                const int m = tm * BM + row;
+                int px = -1;
+                if (m < p.M) {
+                    const int f = m / hw, rem = m - f * hw;
+                    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                    const int kt = tp / (p.KH * p.KW), r2 = tp - kt * (p.KH * p.KW);
+                    const int ky = r2 / p.KW, kx = r2 - ky * p.KW;
+                    const int iy = oy * p.stride - p.ph + ky, ix = ox * p.stride - p.pw + kx;
+                    const int tt = (f % p.T) + kt - p.pt;
+                    if ((unsigned)iy < (unsigned)hlim && (unsigned)ix < (unsigned)wlim && (unsigned)tt < (unsigned)p.T)
+                        px = ((f + kt - p.pt) * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
+                }
+                rowpix[e] = px;
+            }
+            __syncthreads();
+        }
+        tap = s_begin % ntap;
+        c0 = (s_begin / ntap) * BK;
+        fetch_pix();
+    };
+    // one LDS-DMA per 8 panel rows and wave: wave-uniform destination + lane * 16 B; ragged last passes are skipped per wave
+    auto issue_slab = [&](int buf) {
+        char* base = smem + buf * (BM + BN) * PITCH + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) {
+            if ((ACH * RSTEP == BM) || (wave * 8 + j * RSTEP < BM)) {
+                const T* src = pix[j] >= 0 ? A + (long)pix[j] * p.lda + c0 + cA[j] : Z;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + j * RSTEP * PITCH), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            if ((BCH * RSTEP == BN) || (wave * 8 + i * RSTEP < BN)) {
+                const T* src = wptr[i] ? wptr[i] + (long)tap * p.Cin + c0 : Z;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + (BM + i * RSTEP) * PITCH), 16, 0, 0);
+            }
+        }
+        if (++tap == ntap) { tap = 0; c0 += BK; }      // K order: channel-slab major, tap minor (re-reads hit the XCD's L2)
+        if (ntap > 1 && c0 < p.Cin) fetch_pix();
+    };
+
+    f32x4 acc[MB][NB];
+    // fragment offsets inside a 16-row block: lane (lr, lq) reads row lr; 16-bit types: chunk 4h + lq of half h; bf16x3: chunks 2lq, 2lq + 1
+    const int fkey = swz_key<T>(lr);
+    int foff[2];
+    if constexpr (IsX3<T>::value) {
+        foff[0] = lr * PITCH + (((2 * lq) ^ fkey) << 4);
+        foff[1] = lr * PITCH + (((2 * lq + 1) ^ fkey) << 4);
+    } else {
+        foff[0] = lr * PITCH + ((lq ^ fkey) << 4);
+        foff[1] = lr * PITCH + (((4 + lq) ^ fkey) << 4);
+    }
+    const bool a_split = HOT ? false : (p.a_split != 0), w_split = HOT ? true : (p.w_split != 0);
+    auto compute_slab = [&](int buf) {
+        const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
+        const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
+        if constexpr (IsX3<T>::value) {
+            // one 128-byte slab = 32 k = ONE 16x16x32 step; the activation fragments are split once and reused by every column block
+            u32x4 ah[MB], al[MB];
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const u32x4 x0 = *(const u32x4*)(abase + a * 16 * PITCH + foff[0]);
+                const u32x4 x1 = *(const u32x4*)(abase + a * 16 * PITCH + foff[1]);
+                if (a_split) { ah[a] = x0; al[a] = x1; }
+                else split8_bf16(x0, x1, ah[a], al[a]);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const u32x4 y0 = *(const u32x4*)(bbase + b * 16 * PITCH + foff[0]);
+                const u32x4 y1 = *(const u32x4*)(bbase + b * 16 * PITCH + foff[1]);
+                u32x4 bh, bl;
+                if (w_split) { bh = y0; bl = y1; }
+                else split8_bf16(y0, y1, bh, bl);
+#pragma unroll
+                for (int a = 0; a < MB; ++a) mma16_x3(acc[a][b], bh, bl, ah[a], al[a]);      // C rows = n, C cols = m
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 fa[MB];
+#pragma unroll
+                for (int a = 0; a < MB; ++a) fa[a] = *(const u32x4*)(abase + a * 16 * PITCH + foff[h]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const u32x4 fb = *(const u32x4*)(bbase + b * 16 * PITCH + foff[h]);
+#pragma unroll
+                    for (int a = 0; a < MB; ++a) mma16<T>(acc[a][b], fb, fa[a]);
+                }
+            }
+        }
+    };
+
+    // ---- epilogue: acc[a][b][j] is out[m_w0 + 16a + lr][n_w0 + 16b + 4lq + j] -------------------------------------------------------
+    const bool partial = splits > 1;                  // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
+    const int odt = partial ? GEO4D_F32 : p.out_dtype;
+    const int oesz = odt == GEO4D_F32 ? 4 : 2;
+    const bool geglu = !partial && p.act == 2;
+    const int nout = geglu ? (p.N >> 1) : p.N;
+    auto epilogue = [&](int e_tm, int e_tn, long e_bz, int e_kz) {
+        const int m_w0 = e_tm * BM + wr * WTM, n_w0 = e_tn * BN + wc * WTN;
+        void* O = partial ? (void*)((float*)p.workspace + ((long)e_kz * p.batch + e_bz) * (long)p.M * p.N) : p.O;
+        const long ldo = partial ? (long)p.N : p.ldo;
+        const long obase = partial ? 0 : e_bz * p.o_bs;
+        const bool has_res = !partial && p.R != nullptr;
+        const long rbase = e_bz * p.r_bs;
+        // 4-element vectors need 4-element aligned rows and bases (16 B for f32, 8 B for 16-bit outputs)
+        const bool vec_ok = (nout & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)O + obase * oesz) % (4 * oesz)) == 0 &&
+                            (!has_res || ((p.ldr & 3) == 0 && (((uintptr_t)p.R + rbase * oesz) % (4 * oesz)) == 0));
+#pragma unroll
+        for (int a = 0; a < MB; ++a) {
+            const int m = m_w0 + a * 16 + lr;
+            if (m >= p.M) continue;
+            const float brow = (!partial && p.bias && p.bias_per_row) ? p.bias[m] : 0.f;
+            const long rboff = (!partial && p.rowbias) ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
+            if (geglu) {
+                if constexpr (NB % 4 == 0) {
+                    // packed GEGLU weights interleave value / gate in 32-column blocks: 16-blocks 4j, 4j+1 = value, 4j+2, 4j+3 = gate
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if ((b & 3) >= 2) continue;
+                        const int n = n_w0 + 16 * b + 4 * lq;                       // value column; its gate sits 32 columns further
+                        if (n + 32 >= p.N) continue;
+                        const int oc = (n_w0 >> 1) + 32 * (b >> 2) + 16 * (b & 1) + 4 * lq;
+                        float e[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xv = acc[a][b][j] * p.alpha + (p.bias ? p.bias[n + j] : 0.f);
+                            const float gv = acc[a][b + 2 < NB ? b + 2 : b][j] * p.alpha + (p.bias ? p.bias[n + 32 + j] : 0.f);
+                            e[j] = xv * gelu_erf_f(gv);
+                        }
+                        const long oidx = obase + (long)m * ldo + oc;
+                        if (vec_ok) {
+                            if (odt == GEO4D_F32) *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
+                            else if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
+                            else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) store_out(O, oidx + j, e[j], odt);
+                        }
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int n = n_w0 + 16 * b + 4 * lq;
+                if (n >= p.N) continue;
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = acc[a][b][j];
+                const long oidx = obase + (long)m * ldo + n;
+                if (!partial) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = e[j] * p.alpha + brow;
+                        if (n + j < p.N) {
+                            if (p.bias && !p.bias_per_row) v += p.bias[n + j];
+                            if (p.rowbias) v += p.rowbias[rboff + n + j];
+                        }
+                        if (p.act == 1) v = silu_f(v);
+                        else if (p.act == 3) v = gelu_erf_f(v);
+                        e[j] = v;
+                    }
+                }
+                if (vec_ok) {
+                    if (odt == GEO4D_F32) {
+                        if (has_res) {
+                            const f32x4 r = *(const f32x4*)((const float*)p.R + rbase + (long)m * p.ldr + n);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) e[j] += r[j];
+                        }
+                        *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
+                    } else {
+                        if (has_res) {
+                            const u32x2 r = *(const u32x2*)((const unsigned short*)p.R + rbase + (long)m * p.ldr + n);
+                            if (odt == GEO4D_BF16) {
+                                e[0] += __uint_as_float(r[0] << 16); e[1] += __uint_as_float(r[0] & 0xffff0000u);
+                                e[2] += __uint_as_float(r[1] << 16); e[3] += __uint_as_float(r[1] & 0xffff0000u);
+                            } else {
+                                e[0] += f16_bits_to_f32((unsigned short)(r[0] & 0xffffu)); e[1] += f16_bits_to_f32((unsigned short)(r[0] >> 16));
+                                e[2] += f16_bits_to_f32((unsigned short)(r[1] & 0xffffu)); e[3] += f16_bits_to_f32((unsigned short)(r[1] >> 16));
+                            }
+                        }
+                        if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
+                        else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (n + j >= p.N) continue;
+                        float v = e[j];
+                        if (has_res) v += load_res(p.R, rbase + (long)m * p.ldr + n + j, odt);
+                        store_out(O, oidx + j, v, odt);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- persistent tile loop --------------------------------------------------------------------------------------------------------
+    long w = xcd_remap((long)blockIdx.x, G);           // each XCD walks a contiguous range of every round of G tiles
+    if (w >= total) return;
+    setup_tile(w);
+    if (nslab > 0) issue_slab(0);
+    while (true) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ns = nslab;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is drained explicitly before every barrier
+        __syncthreads();
+        for (int s = 0; s < ns; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < ns) issue_slab(buf ^ 1);
+            compute_slab(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                               // next slab landed for every wave, everyone is done reading this one
+        }
+        const int e_tm = tm, e_tn = tn, e_kz = kz;
+        const long e_bz = bz;
+        const long wn = w + G;
+        const bool more = wn < total;
+        if (more) {                                        // the next tile's table + first slab go out BEFORE this tile's epilogue
+            setup_tile(wn);
+            if (nslab > 0) issue_slab(0);
+        }
+        epilogue(e_tm, e_tn, e_bz, e_kz);
+        if (!more) break;
+        w = wn;
+    }
+}
+
+// resident workgroups per launch = CUs x workgroups that fit a CU (queried once per kernel instantiation)
+template <typename T, int BM, int BN, int WM, int WN, bool HOT>
+int launch_v2_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
+    constexpr int smem = v2_smem_bytes<BM, BN>();
+    static int resident = 0;
+    auto kern = conv_gemm_v2_kernel<T, BM, BN, WM, WN, HOT>;
+    if (!resident) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
+            return GEO4D_EIO;
+        }
+        int dev = 0, cus = 0, occ = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, WM * WN * 64, smem) != hipSuccess || cus <= 0 || occ <= 0) {
+            geo4d_set_error("conv_gemm v2: occupancy query failed");
+            return GEO4D_EIO;
+        }
+        resident = cus * occ;
+    }
+    const int tiles_mn = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const long total = (long)tiles_mn * p.batch * splits;
+    // debug_ablate = 2 (tests only): 3 workgroups whatever the problem, so that small shapes walk the persistent tile loop
+    const long cap = p.debug_ablate == 2 ? 3 : resident;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, stream, p, splits, tiles_mn);
+    GEO4D_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long tot = (long)p.batch * p.M * (p.N / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, p, splits);
+        GEO4D_CHECK_LAUNCH();
+    }
+    return GEO4D_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
+    if (p.act == 2 && ((BN / WN / 16) % 4)) {
+        geo4d_set_error("conv_gemm v2: GEGLU needs wave tiles that are a multiple of 64 columns wide");
+        return GEO4D_EINVAL;
+    }
+    if constexpr (IsX3<T>::value) {
+        if (p.w_split && !p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, true>(p, splits, stream);
+    }
+    return launch_v2_kernel<T, BM, BN, WM, WN, false>(p, splits, stream);
+}
+
+// tile hints 21..29: 16x16x32 MFMA, register epilogue, persistent workgroups
+//   21: 256x128, 8 waves (64x64 wave tiles)     22: 256x256, 8 waves (64x128)      23: 160x320, 8 waves (80x80)
+//   24: 160x160, 4 waves (80x80)                25: 128x128, 4 waves (64x64)       26: 128x64, 4 waves (64x32)
+//   27: 64x128, 4 waves (32x64)                 28: 64x64, 4 waves (32x32)         29: 128x256, 8 waves (64x64)
+template <typename T>
+int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
+    if constexpr (std::is_same<T, float>::value) {
+        geo4d_set_error("conv_gemm: tile hints 21..29 serve bf16 / f16 / bf16x3 (the exact-f32 mode stays on hints 0..17)");
+        return GEO4D_EINVAL;
+    } else {
+        if (p.out_nchw || p.gn_colsum || p.debug_ablate == 1) {
+            geo4d_set_error("conv_gemm: tile hints 21..29 have no NCTHW / gn_colsum epilogue");
+            return GEO4D_EINVAL;
+        }
+        int sp = 1;
+        if (p.split_k > 1) {
+            if (!p.workspace || p.act == 2 || (p.N % 8) || (size_t)p.split_k * p.batch * p.M * p.N * 4 > p.workspace_bytes ||
+                p.K / (BKC * Elem<T>::EPC) / p.split_k < 1) {
+                geo4d_set_error("conv_gemm: split_k not applicable (workspace too small / epilogue not splittable)");
+                return GEO4D_EINVAL;
+            }
+            sp = p.split_k;
+        }
+        switch (p.tile_hint) {
+            case 21: return launch_v2_cfg<T, 256, 128, 4, 2>(p, sp, stream);
+            case 22: return launch_v2_cfg<T, 256, 256, 4, 2>(p, sp, stream);
+            case 23: return launch_v2_cfg<T, 160, 320, 2, 4>(p, sp, stream);
+            case 24: return launch_v2_cfg<T, 160, 160, 2, 2>(p, sp, stream);
+            case 25: return launch_v2_cfg<T, 128, 128, 2, 2>(p, sp, stream);
+            case 26: return launch_v2_cfg<T, 128, 64, 2, 2>(p, sp, stream);
+            case 27: return launch_v2_cfg<T, 64, 128, 2, 2>(p, sp, stream);
+            case 28: return launch_v2_cfg<T, 64, 64, 2, 2>(p, sp, stream);
+            case 29: return launch_v2_cfg<T, 128, 256, 2, 4>(p, sp, stream);
+        }
+        geo4d_set_error("conv_gemm: unknown tile_hint");
+        return GEO4D_EINVAL;
+    }
+}
+
+}  // namespace geo4d_gemm

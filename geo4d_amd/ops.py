@@ -73,7 +73,10 @@ import os as _os
 
 _TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950.json")
 _TUNE = None
-_CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1), (17, 2), (16, 2), (17, 8), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1)]
+_CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1), (17, 2), (16, 2), (17, 8), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1),
+               # round 3 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups; refused for f32 / NCTHW outputs)
+               (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (21, 2), (21, 4), (21, 8), (22, 2), (22, 4),
+               (23, 2), (24, 2), (24, 4), (25, 2), (25, 4), (25, 8), (26, 2), (26, 4), (27, 2), (27, 4), (28, 2), (28, 4), (28, 8), (29, 2)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
 # GEMM epilogues can emit the next GroupNorm's column sums (gn_stats=True call sites). OFF by default: measured on MI355X the fused
 # path is correct but not faster yet (round 2: -3.5 % bf16x3, -7 % bf16 with the first finalize kernel) - the epilogue work lands on
@@ -191,6 +194,8 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
             and (residual is None or (residual.data_ptr() % 16 == 0 and (ldr * out.element_size()) % 16 == 0)):
         # the consumer GroupNorm's statistics pass, for free: per 32-row block and column (sum, sum of squares) from the epilogue
         split_k = 1
+        if tile_hint >= 21:          # the second-generation tiles have no gn_colsum epilogue
+            tile_hint = 0
         cs = torch.empty((M // 32, N, 2), device=out.device, dtype=torch.float32)
         p.gn_colsum = cs.data_ptr()
         out._gn_colsum = cs
@@ -244,7 +249,7 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1
     return out, Hout, Wout
 
 
-def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None, gn_stats=False):
+def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None, gn_stats=False, tile_hint=0, split_k=0):
     """nn.Conv3d kernel (3,1,1), padding (1,0,0) on tokens [(b t) hw, C]; w packed [N, 3*C]."""
     Cin = x.shape[1]
     N = w.shape[0]
@@ -254,7 +259,7 @@ def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None, gn_stats=Fal
         out = torch.empty((M, N), device=x.device, dtype=x.dtype)
     return conv_gemm(x, w, out, M=M, N=N, K=3 * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), T=T, Hin=HW, Win=1,
                      Hout=HW, Wout=1, KT=3, pt=1, bias=bias, residual=residual,
-                     ldr=_ld(residual) if residual is not None else 0, gn_stats=gn_stats)
+                     ldr=_ld(residual) if residual is not None else 0, gn_stats=gn_stats, tile_hint=tile_hint, split_k=split_k)
 
 
 def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias_per_row=False, alpha=1.0, x3=False):

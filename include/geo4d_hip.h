@@ -60,9 +60,13 @@ typedef struct geo4d_conv_gemm_t {
                             8 waves, one tile per CU: 11 = 256x128, 13 = 256x256; deep-ring A/B variants:
                             12 = 256x128 x 3 stages, 14 = 128x128 x 4 stages; 16 = 160x320 with 10 waves
                             (N = 320 layers: one tile per CU at M = 40960), 17 = 160x160 with 5 waves; no
-                            GEGLU on 16 / 17. Others: -EINVAL */
+                            GEGLU on 16 / 17. Round 3, bf16 / f16 / bf16x3 only (16x16x32 MFMA, register epilogue, persistent
+                            workgroups; no NCTHW output, no gn_colsum): 21 = 256x128, 22 = 256x256, 23 = 160x320 (8 waves,
+                            80x80 wave tiles), 24 = 160x160 (4 waves), 25 = 128x128, 26 = 128x64, 27 = 64x128, 28 = 64x64,
+                            29 = 128x256; GEGLU on 21, 22, 25, 27, 29. Others: -EINVAL */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
-    int debug_ablate;    /* 0 in production. 1 (bf16x3 profiling only): skip the in-register hi/lo split -> WRONG results */
+    int debug_ablate;    /* 0 in production. 1 (bf16x3 profiling only): skip the in-register hi/lo split -> WRONG results;
+                            2 (tests only, tile hints >= 21): launch 3 persistent workgroups whatever the problem size */
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */

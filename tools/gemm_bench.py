@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--vendor", action="store_true", help="also time the vendor library on the same shape (hipBLASLt via F.linear, MIOpen via F.conv2d channels_last): a calibration point, never used by the product path")
     ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
+    ap.add_argument("--explore2", action="store_true", help="per shape: best 32x32-MFMA configuration (tile hints 1..17) vs best second-generation one (21..29), and every 21..29 tile at split 1")
     ap.add_argument("--ablate", type=int, default=0, help="bf16x3 only: 1 = skip the in-register operand split (wrong numbers; measures its cost)")
     args = ap.parse_args()
     ops.DEBUG_ABLATE = args.ablate
@@ -135,12 +136,33 @@ def main():
             res.sort()
             print("    auto %.1f us | best: %s" % (us, "  ".join("t%d/s%d %.1f" % (t, s2, u) for u, t, s2 in res[:6])))
             us = min(us, res[0][0])
+        if args.explore2:
+            def sweep(tiles):
+                res = []
+                for tile in tiles:
+                    for split in (1, 2, 4, 8):
+                        try:
+                            res.append((timeit(tile=tile, split=split), tile, split))
+                        except RuntimeError:
+                            pass
+                return sorted(res)
+            v1, v2 = sweep((1, 2, 3, 4, 11, 13, 16, 17)), sweep(range(21, 30))
+            tot2 = globals().setdefault("_TOT2", [0.0, 0.0])
+            tot2[0] += v1[0][0] * cnt / 1e3
+            tot2[1] += v2[0][0] * cnt / 1e3
+            print("    table %.1f us | v1 best t%d/s%d %.1f | v2 best t%d/s%d %.1f (%.2fx) | v2 split 1: %s" % (
+                us, v1[0][1], v1[0][2], v1[0][0], v2[0][1], v2[0][2], v2[0][0], v1[0][0] / v2[0][0],
+                "  ".join("t%d %.1f" % (t, u) for u, t, s2 in sorted(v2, key=lambda r: r[1]) if s2 == 1)))
+            us = min(us, v1[0][0], v2[0][0])
         tf = 2.0 * M * N * K / us / 1e6
         tot_ms += us * cnt / 1e3
         tot_tf += 2.0 * M * N * K * cnt / 1e12
         print(f"{name:34s} {M:8d} {N:6d} {K:6d} {us:9.1f} {tf:8.1f}  x{cnt:3d} -> {us * cnt / 1e3:7.2f}" + (f"   vendor {vend:8.1f} us ({us / vend:4.2f}x ours/vendor)" if vend else ""))
     if tot_ms:
         print(f"U-Net GEMM census: {tot_tf:.2f} TFLOP in {tot_ms:.1f} ms = {tot_tf / tot_ms * 1e3:.0f} TF/s")
+    if args.explore2:
+        t1, t2 = globals()["_TOT2"]
+        print(f"census with the best 32x32-MFMA configuration per shape: {t1:.1f} ms; with the best 21..29 configuration per shape: {t2:.1f} ms")
 
 
 if __name__ == "__main__":
