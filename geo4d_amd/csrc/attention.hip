@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
                     float e[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) e[j] = res[4 * i + j];
-                    *(u32x4*)(op + dcol) = f32_to_chunk<T>(e);
+                    if (p.split_out) store_split4(op - h * 64, (h * 64 + dcol) >> 2, e);       // pre-split operand of the to_out GEMM
+                    else *(u32x4*)(op + dcol) = f32_to_chunk<T>(e);
                 }
             }
         }
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
 template <typename T>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ k, long ldk,
                                                             const T* __restrict__ v, long ldv, T* __restrict__ o, long ldo, int B,
-                                                            int Tn, int HW, int H, float scale) {
+                                                            int Tn, int HW, int H, float scale, int split_out) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int DCH = 64 / EPC;
     __shared__ __attribute__((aligned(16))) float qf[4][16][64];
@@ -433,7 +434,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
                 u32x2 o2; o2[0] = c[0]; o2[1] = c[1];
                 *(u32x2*)(op + d0) = o2;
             } else {
-                *(u32x4*)(op + d0) = f32_to_chunk<T>(o4);
+                if (split_out) store_split4(op - h * 64, (h * 64 + d0) >> 2, o4);
+                else *(u32x4*)(op + d0) = f32_to_chunk<T>(o4);
             }
         }
     }
@@ -457,6 +459,7 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     }
     if (!p.zeros || ((uintptr_t)p.zeros % 16)) { geo4d_set_error("attention: `zeros` must point at 16 zero bytes"); return GEO4D_EINVAL; }
     if (p.H > 65535 || p.B > 65535) { geo4d_set_error("attention: grid too large"); return GEO4D_EINVAL; }
+    if (p.split_out && esz != 4) { geo4d_set_error("attention: split_out is the producer format of the 4-byte storage modes (f32 / bf16x3)"); return GEO4D_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     // variant: 0 = host default; explicit: 1 = 128 rows / workgroup at 3 waves per SIMD (round-1 kernel), 2 = the same at 4 waves
     // per SIMD (128-VGPR budget), 3 = 256 rows / workgroup, two query blocks per wave (self-attention only)
@@ -498,7 +501,12 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
 
 extern "C" int geo4d_temporal_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                                         int B, int T, int HW, int H, int head_dim, float scale, int dtype, void* stream) {
+    return geo4d_temporal_attention2(q, ldq, k, ldk, v, ldv, o, ldo, B, T, HW, H, head_dim, scale, dtype, 0, stream);
+}
+extern "C" int geo4d_temporal_attention2(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                                         int B, int T, int HW, int H, int head_dim, float scale, int dtype, int split_out, void* stream) {
     const int esz = dtype == GEO4D_F32 ? 4 : 2;
+    if (split_out && dtype != GEO4D_F32) { geo4d_set_error("temporal_attention: split_out needs f32 storage"); return GEO4D_EINVAL; }
     if (dtype < 0 || dtype > 2 || B <= 0 || T <= 0 || HW <= 0 || H <= 0) { geo4d_set_error("temporal_attention: bad arguments"); return GEO4D_EINVAL; }
     if (T > 16) { geo4d_set_error("temporal_attention: T > 16 not built (yaml temporal_length: 16)"); return GEO4D_ENOTSUP; }
     if (head_dim != 64) { geo4d_set_error("temporal_attention: only d_head = 64 is built"); return GEO4D_ENOTSUP; }
@@ -510,9 +518,9 @@ extern "C" int geo4d_temporal_attention(const void* q, long ldq, const void* k, 
     const dim3 grid((unsigned)((units + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case GEO4D_F32: hipLaunchKernelGGL(temporal_attn_kernel<float>, grid, dim3(256), 0, st, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)o, ldo, B, T, HW, H, scale); break;
-        case GEO4D_BF16: hipLaunchKernelGGL(temporal_attn_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, B, T, HW, H, scale); break;
-        default: hipLaunchKernelGGL(temporal_attn_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)q, ldq, (const f16_t*)k, ldk, (const f16_t*)v, ldv, (f16_t*)o, ldo, B, T, HW, H, scale); break;
+        case GEO4D_F32: hipLaunchKernelGGL(temporal_attn_kernel<float>, grid, dim3(256), 0, st, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)o, ldo, B, T, HW, H, scale, split_out); break;
+        case GEO4D_BF16: hipLaunchKernelGGL(temporal_attn_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, B, T, HW, H, scale, 0); break;
+        default: hipLaunchKernelGGL(temporal_attn_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)q, ldq, (const f16_t*)k, ldk, (const f16_t*)v, ldv, (f16_t*)o, ldo, B, T, HW, H, scale, 0); break;
     }
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;

@@ -171,6 +171,25 @@ __device__ __forceinline__ void split8_bf16(const u32x4& c0, const u32x4& c1, u3
                         __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
     split8_bf16(x, hi, lo);
 }
+// bf16x3 producers: store 4 (8) consecutive f32 K-elements of a row in the PRE-SPLIT operand format (per 8 K-elements: 8 x bf16 hi |
+// 8 x bf16 lo, 32 bytes - what pack.py split_bf16 writes for weights and what conv_gemm's a_split consumes). `row_base` is the row's
+// first byte, `cc` the index of the 4-element (16-byte) f32 chunk inside the row: half `cc & 1` of group `cc >> 1`.
+__device__ __forceinline__ void store_split4(void* row_base, int cc, const float* e) {
+    const unsigned int h0 = f32x2_to_bf16x2(e[0], e[1]), h1 = f32x2_to_bf16x2(e[2], e[3]);
+    const unsigned int l0 = f32x2_to_bf16x2(e[0] - __uint_as_float(h0 << 16), e[1] - __uint_as_float(h0 & 0xffff0000u));
+    const unsigned int l1 = f32x2_to_bf16x2(e[2] - __uint_as_float(h1 << 16), e[3] - __uint_as_float(h1 & 0xffff0000u));
+    char* g = (char*)row_base + (cc >> 1) * 32 + (cc & 1) * 8;
+    *(u32x2*)g = u32x2{h0, h1};
+    *(u32x2*)(g + 16) = u32x2{l0, l1};
+}
+__device__ __forceinline__ void store_split8(void* row_base, int group8, const float* e) {
+    u32x4 hi, lo;
+    split8_bf16(e, hi, lo);
+    char* g = (char*)row_base + group8 * 32;
+    *(u32x4*)g = hi;
+    *(u32x4*)(g + 16) = lo;
+}
+
 // acc += a.b with a = ah + al, b = bh + bl, dropping al.bl (2^-16 x 2^-16): three dense bf16 MFMAs, fp32 accumulate
 __device__ __forceinline__ void mma_x3(f32x16& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);

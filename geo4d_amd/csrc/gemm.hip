@@ -55,7 +55,13 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     const int bk = BKC * epc;
     if (p.dtype < 0 || p.dtype > 3 || p.out_dtype < 0 || p.out_dtype > 2) { geo4d_set_error("conv_gemm: bad dtype"); return GEO4D_EINVAL; }
     if (p.dtype != GEO4D_BF16X3 && (p.a_split || p.w_split)) { geo4d_set_error("conv_gemm: a_split / w_split are bf16x3 (dtype 3) options"); return GEO4D_EINVAL; }
-    if (p.a_split && p.KT * p.KH * p.KW != 1) { geo4d_set_error("conv_gemm: a pre-split A operand must be a plain matrix (1 tap)"); return GEO4D_EINVAL; }
+    if (p.o_split) {
+        const int nst = p.act == 2 ? p.N / 2 : p.N;
+        if (p.dtype != GEO4D_BF16X3 || p.out_dtype != GEO4D_F32 || p.out_nchw || p.R || p.gn_colsum || (nst % 8) || (p.ldo % 4) || (p.o_bs % 4) || ((uintptr_t)p.O % 16)) {
+            geo4d_set_error("conv_gemm: o_split needs dtype bf16x3, f32 row-major output, stored columns % 8 == 0, aligned rows, no residual / gn_colsum");
+            return GEO4D_EINVAL;
+        }
+    }
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) { geo4d_set_error("conv_gemm: empty problem"); return GEO4D_EINVAL; }
     if (p.KT <= 0 || p.KH <= 0 || p.KW <= 0 || p.KT * p.KH * p.KW > MAXTAP) { geo4d_set_error("conv_gemm: at most 9 taps"); return GEO4D_EINVAL; }
     if (p.Cin % bk || p.K != p.Cin * p.KT * p.KH * p.KW) { geo4d_set_error("conv_gemm: Cin must be a multiple of the 128-byte K slab and K = taps*Cin"); return GEO4D_EINVAL; }

@@ -38,7 +38,7 @@ constexpr int smem_bytes() {
 // HOT (bf16x3 only): the layout of the two operands is fixed at compile time to the one every conv / linear of the networks uses
 // (raw f32 activations, pre-split weights), so the fragment loop carries no per-fragment branch on the layout flags — measured:
 // uniform branches inside this K loop cost ~10 % (profiles/r02_gemm_x3.md). The generic build serves linear_t / batched GEMMs.
-template <typename T, int BM, int BN, int WM, int WN, int ST, bool HOT = false>
+template <typename T, int BM, int BN, int WM, int WN, int ST, int HOT = 0>   // HOT: 0 generic, 1 = raw A x split W, 2 = split A x split W
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_conv_gemm_t p) {
     constexpr int NT = WM * WN * 64;              // 256 threads (4 waves) or 512 (8 waves: one 256x128 tile per CU)
     constexpr int EPC = Elem<T>::EPC;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
     }
     // debug_ablate = 1 (tools/gemm_bench.py --ablate): treat raw f32 operands as if pre-split, i.e. skip the in-register split -
     // WRONG numbers, used only to measure what the split's VALU work costs
-    const bool a_split = HOT ? false : (p.a_split != 0 || p.debug_ablate == 1), w_split = HOT ? true : (p.w_split != 0 || p.debug_ablate == 1);
+    const bool a_split = HOT ? (HOT == 2) : (p.a_split != 0 || p.debug_ablate == 1), w_split = HOT ? true : (p.w_split != 0 || p.debug_ablate == 1);
     auto compute_slab = [&](int buf) {
         const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
         const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
@@ -541,13 +541,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const geo4d_conv_gem
         if (p.bias && !p.bias_per_row) v += p.bias[n + j];
         if (p.rowbias) v += p.rowbias[rboff + n + j];
         if (p.act == 1) v = silu_f(v);
-                        else if (p.act == 3) v = gelu_erf_f(v);
+        else if (p.act == 3) v = gelu_erf_f(v);
         if (p.R) v += load_res(p.R, bz * p.r_bs + (long)m * p.ldr + n + j, p.out_dtype);
-        store_out(p.O, bz * p.o_bs + (long)m * p.ldo + n + j, v, p.out_dtype);
+        e[j] = v;
     }
+    if (p.o_split) {
+        store_split8((float*)p.O + bz * p.o_bs + (long)m * p.ldo, n >> 3, e);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) store_out(p.O, bz * p.o_bs + (long)m * p.ldo + n + j, e[j], p.out_dtype);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int ST, bool HOT>
+template <typename T, int BM, int BN, int WM, int WN, int ST, int HOT>
 int launch_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     constexpr int smem = smem_bytes<BM, BN, WM, WN, ST>();
     static bool attr_set = false;
@@ -574,10 +580,11 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     }
     int rc;
     if constexpr (IsX3<T>::value) {
-        if (p.w_split && !p.a_split && p.debug_ablate == 0) rc = launch_kernel<T, BM, BN, WM, WN, ST, true>(p, splits, stream);
-        else rc = launch_kernel<T, BM, BN, WM, WN, ST, false>(p, splits, stream);
+        if (p.w_split && !p.a_split && p.debug_ablate == 0) rc = launch_kernel<T, BM, BN, WM, WN, ST, 1>(p, splits, stream);
+        else if (p.w_split && p.a_split && p.debug_ablate == 0) rc = launch_kernel<T, BM, BN, WM, WN, ST, 2>(p, splits, stream);
+        else rc = launch_kernel<T, BM, BN, WM, WN, ST, 0>(p, splits, stream);
     } else {
-        rc = launch_kernel<T, BM, BN, WM, WN, ST, false>(p, splits, stream);
+        rc = launch_kernel<T, BM, BN, WM, WN, ST, 0>(p, splits, stream);
     }
     if (rc != GEO4D_OK) return rc;
     if (splits > 1) {
@@ -588,9 +595,9 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     return GEO4D_OK;
 }
 
-}  // namespace geo4d_gemm
-#include "gemm_kernel_v2.h"   // tile hints 21..29: 16x16x32 MFMA, register epilogue, persistent workgroups
-namespace geo4d_gemm {
+// tile hints 21..39 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups) are instantiated in their own
+// translation units (gemm_v2_*.hip) so that the two kernel generations compile in parallel
+template <typename T> int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream);
 
 // Tile choice: score = MFMA efficiency of the tile shape x useful fraction x how full the last wave of
 // workgroups is (2 workgroups fit per CU by LDS => 512 slots on 256 CUs). Split-K multiplies the workgroup count
@@ -601,6 +608,11 @@ template <typename T>
 int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     static constexpr TileCfg cfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.80f}, {64, 64, 0.62f}, {128, 32, 0.50f}};
     if (p.tile_hint >= 21) return launch_v2_typed<T>(p, stream);
+    if (p.o_split) {     // the pre-split output format lives in the register epilogue of the second-generation kernel only
+        geo4d_conv_gemm_t q = p;
+        q.tile_hint = p.tile_hint == 13 ? 22 : (p.tile_hint == 11 || p.tile_hint == 12) ? 21 : p.tile_hint == 3 ? 27 : 25;
+        return launch_v2_typed<T>(q, stream);
+    }
     if (p.tile_hint >= 11) {
         // explicit big-tile / deep-ring configurations, chosen by the host tuning table only. What they trade:
         // a CU can hold at most ~128 KB of LDS-DMA destinations, and a stage lands ~1 us after it is issued, so the

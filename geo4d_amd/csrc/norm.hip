@@ -23,15 +23,13 @@ __host__ __device__ inline int gn_rows_per_chunk(int HW) {
 
 // ---- GroupNorm pass 1: per (frame, row-chunk, group) partial (n, mean, M2) ----------------
 template <typename T>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, long ldx, int HW, int C, int G,
-                                                         int R, int nchunk, float* __restrict__ part) {
+__device__ __forceinline__ void gn_partial_body(char* smem, const T* __restrict__ x, long ldx, int HW, int C, int G,
+                                                int R, int nchunk, float* __restrict__ part, int chunk, int f) {
     constexpr int EPC = Elem<T>::EPC;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float* stage = (float*)smem;               // [256][2*EPC]
     float* chs = stage + 256 * 2 * EPC;        // [C] channel sums
     float* chq = chs + C;                      // [C] channel sums of squares
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, f = blockIdx.y;
     const int CPR = C / EPC;
     const int TC = CPR < 256 ? CPR : 256;
     const int TR = 256 / TC;
@@ -91,6 +89,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
         o[0] = n; o[1] = mean; o[2] = m2;
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, long ldx, int HW, int C, int G,
+                                                         int R, int nchunk, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gn_partial_body<T>(smem, x, ldx, HW, C, G, R, nchunk, part, blockIdx.x, blockIdx.y);
+}
 
 // ---- GroupNorm pass 2: merge partials -> (mean, rstd) per (stat, group) --------------------
 // one wave per (stat, group): lanes merge strided subsets with Chan's formula, then a fixed-order xor-butterfly merges
@@ -105,14 +109,9 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
         n = nn;
     }
 }
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int fps, int G,
-                                                          float eps, float* __restrict__ stats, int nstat) {
-    const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= nstat * G) return;
-    const int stat = unit / G, grp = unit - stat * G;
+// one wave merges the fps * nchunk partials of (stat, grp); lane 0 returns (mean, rstd). Same order in the 3-launch and the fused path.
+__device__ __forceinline__ f32x2 gn_merge_unit(const float* __restrict__ part, int total, int stat, int grp, int G, float eps, int lane) {
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    const int total = fps * nchunk;
     for (int i = lane; i < total; i += 64) {
         const float* pp = part + (((long)stat * total + i) * G + grp) * 3;
         chan_merge(n, mean, m2, pp[0], pp[1], pp[2]);
@@ -126,10 +125,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         chan_merge(n0, a0, q0, n1, a1, q1);
         n = n0; mean = a0; m2 = q0;
     }
+    return f32x2{mean, 1.0f / sqrtf(m2 / n + eps)};
+}
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int fps, int G,
+                                                          float eps, float* __restrict__ stats, int nstat) {
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= nstat * G) return;
+    const int stat = unit / G, grp = unit - stat * G;
+    const f32x2 r = gn_merge_unit(part, fps * nchunk, stat, grp, G, eps, lane);
     if (lane == 0) {
-        const float var = m2 / n;
-        stats[((long)stat * G + grp) * 2 + 0] = mean;
-        stats[((long)stat * G + grp) * 2 + 1] = 1.0f / sqrtf(var + eps);
+        stats[((long)stat * G + grp) * 2 + 0] = r[0];
+        stats[((long)stat * G + grp) * 2 + 1] = r[1];
     }
 }
 
@@ -171,14 +178,13 @@ __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __re
 }
 
 // ---- GroupNorm pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU -----------------
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
-                                                       int HW, int C, int G, int fps, int R,
-                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int act) {
+// st: (mean, rstd) per group of this frame's statistic (global memory or LDS)
+template <typename T, bool SPLIT>
+__device__ __forceinline__ void gn_apply_body(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                              int HW, int C, int G, int R, const float* st, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int act, int chunk, int f) {
     constexpr int EPC = Elem<T>::EPC;
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, f = blockIdx.y;
     const int CPR = C / EPC;
     const int TC = CPR < 256 ? CPR : 256;
     const int TR = 256 / TC;
@@ -187,7 +193,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int row0 = chunk * R;
     const int rows = min(R, HW - row0);
     const int cpg = C / G;
-    const float* st = stats + (long)(f / fps) * G * 2;
     const T* xb = x + ((long)f * HW + row0) * ldx;
     T* yb = y + ((long)f * HW + row0) * ldy;
     for (int cc = tc; cc < CPR; cc += TC) {
@@ -219,14 +224,73 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                     if (act == 1) o = silu_f(o);
                     e[j] = o;
                 }
-                *(u32x4*)(yb + (long)ru * ldy + cc * EPC) = f32_to_chunk<T>(e);
+                if constexpr (SPLIT) store_split4(yb + (long)ru * ldy, cc, e);          // (ldy counts K elements of 4 bytes, like ldx)
+                else *(u32x4*)(yb + (long)ru * ldy + cc * EPC) = f32_to_chunk<T>(e);
             }
         }
     }
 }
+template <typename T, bool SPLIT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                       int HW, int C, int G, int fps, int R,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int act) {
+    const int f = blockIdx.y;
+    gn_apply_body<T, SPLIT>(x, ldx, y, ldy, HW, C, G, R, stats + (long)(f / fps) * G * 2, gamma, beta, act, blockIdx.x, f);
+}
+
+// ---- GroupNorm in ONE launch: statistics pass, grid-wide barrier, merge of this frame's partials, apply pass -------------------
+// Every workgroup owns the same (row chunk, frame) in both passes, so the second read of x comes from its XCD's L2 / the Infinity
+// Cache instead of HBM for the U-Net's tensors, and the 166 GroupNorms of a forward cost 166 launches instead of 498.
+// The barrier is a self-resetting counter + generation pair in a persistent, zero-initialised device buffer (stream-ordered use:
+// one GroupNorm at a time per buffer): a workgroup reads the generation BEFORE it arrives, the last arriver clears the counter and
+// bumps the generation. Release / acquire at agent scope around it (cdna_hip_programming.md Guideline 16). The host only takes this
+// path when all workgroups are co-resident; a spin budget turns a scheduling accident into a trap instead of a hung GPU.
+// Results are bit-identical to the three-launch path (same partials, same merge order).
+template <typename T, bool SPLIT>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int HW, int C, int G,
+                                                       int fps, int R, int nchunk, float eps, float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                       unsigned int* __restrict__ bar) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float st[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, f = blockIdx.y;
+    unsigned int gen0 = 0;
+    if (tid == 0) gen0 = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gn_partial_body<T>(smem, x, ldx, HW, C, G, R, nchunk, part, chunk, f);
+    __syncthreads();                                   // this workgroup's partial (written by threads < G) is issued
+    if (tid == 0) {
+        const unsigned int nwg = gridDim.x * gridDim.y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int old = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nwg - 1) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            long spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1L << 22)) __builtin_trap();       // ~seconds: not co-resident after all - fail loudly, never hang
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const int stat = f / fps;
+    for (int grp = wave; grp < G; grp += 4) {              // one wave per group, fixed order inside (same as gn_finalize_kernel)
+        const f32x2 r = gn_merge_unit(part, fps * nchunk, stat, grp, G, eps, lane);
+        if (lane == 0) { st[grp * 2] = r[0]; st[grp * 2 + 1] = r[1]; }
+    }
+    __syncthreads();
+    gn_apply_body<T, SPLIT>(x, ldx, y, ldy, HW, C, G, R, st, gamma, beta, act, chunk, f);
+}
 
 // ---- LayerNorm: one wave per row, row held in registers ------------------------------------
-template <typename T, int MAXC>  // MAXC = chunks per lane
+template <typename T, int MAXC, bool SPLIT = false>  // MAXC = chunks per lane; SPLIT (f32 only): write the pre-split bf16x3 operand format
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int M, int C,
                                                  float eps, const float* __restrict__ gamma, const float* __restrict__ beta) {
     constexpr int EPC = Elem<T>::EPC;
@@ -270,7 +334,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
                 const int c = cc * EPC + j;
                 o[j] = (e[i][j] - mean) * rstd * gamma[c] + beta[c];
             }
-            *(u32x4*)(y + row * ldy + cc * EPC) = f32_to_chunk<T>(o);
+            if constexpr (SPLIT) store_split4(y + row * ldy, cc, o);
+            else *(u32x4*)(y + row * ldy + cc * EPC) = f32_to_chunk<T>(o);
         }
     }
 }
@@ -303,15 +368,44 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = tid; c < cols; c += 256) Elem<T>::st(yr + c, __expf(xr[c] * scale - m) * inv);
 }
 
-template <typename T>
+// workgroups of gn_fused_kernel<T, SPLIT> that are resident at once (CUs x occupancy), cached per instantiation
+template <typename T, bool SPLIT>
+int gn_fused_capacity(size_t smem) {
+    static int cap = 0;
+    if (!cap) {
+        int dev = 0, cus = 0, occ = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gn_fused_kernel<T, SPLIT>, 256, smem) != hipSuccess) return 0;
+        cap = cus * occ;
+    }
+    return cap;
+}
+
+template <typename T, bool SPLIT>
 int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     constexpr int EPC = Elem<T>::EPC;
-    const int R = gn_rows_per_chunk(p.HW);
-    const int nchunk = (p.HW + R - 1) / R;
+    int R = gn_rows_per_chunk(p.HW);
+    int nchunk = (p.HW + R - 1) / R;
     float* part = (float*)p.workspace;
-    float* stats = part + (size_t)p.F * nchunk * p.groups * 3;
     const size_t smem = (size_t)256 * 2 * EPC * 4 + (size_t)2 * p.C * 4;
     const int nstat = p.F / p.frames_per_stat;
+    if (p.barrier && !p.colsum) {
+        // one launch when every workgroup can be resident (the grid-wide barrier needs that); larger tensors take fewer, longer chunks
+        int cap = gn_fused_capacity<T, SPLIT>(smem);
+        if (cap > 2048) cap = 2048;
+        if (cap >= p.F) {
+            if ((long)nchunk * p.F > cap) {
+                const int per_frame = cap / p.F;
+                R = ((p.HW + per_frame - 1) / per_frame + 7) / 8 * 8;
+                nchunk = (p.HW + R - 1) / R;
+            }
+            hipLaunchKernelGGL((gn_fused_kernel<T, SPLIT>), dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy,
+                               p.HW, p.C, p.groups, p.frames_per_stat, R, nchunk, p.eps, part, p.gamma, p.beta, p.act, (unsigned int*)p.barrier);
+            GEO4D_CHECK_LAUNCH();
+            return GEO4D_OK;
+        }
+    }
+    float* stats = part + (size_t)p.F * nchunk * p.groups * 3;
     if (p.colsum) {     // statistics already summed per 32-row block by the producing GEMM's epilogue: no pass over x
         hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nstat * p.groups), dim3(256), 0, s, p.colsum, p.frames_per_stat * (p.HW / 32),
                            p.C, p.groups, p.eps, stats, nstat);
@@ -324,19 +418,19 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
                            p.groups, p.eps, stats, nstat);
         GEO4D_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
+    hipLaunchKernelGGL((gn_apply_kernel<T, SPLIT>), dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
                        p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act);
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 int layernorm_typed(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* g, const float* b,
                     hipStream_t s) {
     constexpr int EPC = Elem<T>::EPC;
     const int per_lane = (C / EPC + 63) / 64;
     const dim3 grid((M + 3) / 4);
-#define LN_LAUNCH(MC) hipLaunchKernelGGL((ln_kernel<T, MC>), grid, dim3(256), 0, s, (const T*)x, ldx, (T*)y, ldy, M, C, eps, g, b)
+#define LN_LAUNCH(MC) hipLaunchKernelGGL((ln_kernel<T, MC, SPLIT>), grid, dim3(256), 0, s, (const T*)x, ldx, (T*)y, ldy, M, C, eps, g, b)
     if (per_lane <= 1) LN_LAUNCH(1);
     else if (per_lane <= 2) LN_LAUNCH(2);
     else if (per_lane <= 3) LN_LAUNCH(3);
@@ -370,11 +464,13 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
     if (p.workspace_bytes < geo4d_groupnorm_workspace(p.F, p.HW, p.groups, p.frames_per_stat)) { geo4d_set_error("groupnorm: workspace too small"); return GEO4D_EINVAL; }
     if (p.F > 65535) { geo4d_set_error("groupnorm: too many frames"); return GEO4D_EINVAL; }
     if (p.colsum && ((p.HW % 32) || ((uintptr_t)p.colsum % 8))) { geo4d_set_error("groupnorm: colsum needs HW % 32 == 0"); return GEO4D_EINVAL; }
+    if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8))) { geo4d_set_error("groupnorm: split_out is the bf16x3 producer format: f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
+    if (p.barrier && ((uintptr_t)p.barrier % 8)) { geo4d_set_error("groupnorm: barrier alignment"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {
-        case GEO4D_F32: return groupnorm_typed<float>(p, s);
-        case GEO4D_BF16: return groupnorm_typed<bf16_t>(p, s);
-        default: return groupnorm_typed<f16_t>(p, s);
+        case GEO4D_F32: return p.split_out ? groupnorm_typed<float, true>(p, s) : groupnorm_typed<float, false>(p, s);
+        case GEO4D_BF16: return groupnorm_typed<bf16_t, false>(p, s);
+        default: return groupnorm_typed<f16_t, false>(p, s);
     }
 }
 
@@ -391,6 +487,15 @@ extern "C" int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M
         case GEO4D_BF16: return layernorm_typed<bf16_t>(x, ldx, y, ldy, M, C, eps, gamma, beta, s);
         default: return layernorm_typed<f16_t>(x, ldx, y, ldy, M, C, eps, gamma, beta, s);
     }
+}
+
+extern "C" int geo4d_layernorm_split(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
+                                     const float* beta, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || (ldx * 4) % 16 || (ldy * 4) % 16 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) {
+        geo4d_set_error("layernorm_split: bad arguments (f32 input, C % 8 == 0, 16-byte aligned rows)");
+        return GEO4D_EINVAL;
+    }
+    return layernorm_typed<float, true>(x, ldx, y, ldy, M, C, eps, gamma, beta, (hipStream_t)stream);
 }
 
 static int softmax_rows_launch(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,

@@ -34,9 +34,28 @@ def is_split(w, other):
     return w.dtype == torch.bfloat16 and other.dtype == torch.float32
 
 
+class SplitAct(torch.Tensor):
+    """A bf16 [rows, 2K] activation in the pre-split bf16x3 operand format (per 8 K-elements: 8 x bf16 hi | 8 x bf16 lo), written by
+    the producers that feed GEMMs (GroupNorm / LayerNorm / attention / GEGLU epilogue with split_out) so that conv_gemm does not
+    split the fragments again in its K loop. A Tensor subclass only to make the format visible to conv_gemm (and to fail loudly if
+    such a buffer reaches a kernel that expects plain f32)."""
+    @staticmethod
+    def wrap(t):
+        return t.as_subclass(SplitAct)
+
+
+def new_split(rows, k, device):
+    return SplitAct.wrap(torch.empty((rows, 2 * k), device=device, dtype=torch.bfloat16))
+
+
+def act_k(x):
+    """Channels (K elements) of an activation matrix: a SplitAct stores 2 bf16 per element."""
+    return x.shape[1] // 2 if isinstance(x, SplitAct) else x.shape[1]
+
+
 def kdim(w, other):
     """Logical K extent of a 2-D operand (a pre-split operand stores 2 bf16 per K element)."""
-    return w.shape[1] // 2 if is_split(w, other) else w.shape[1]
+    return w.shape[1] // 2 if (is_split(w, other) or isinstance(other, SplitAct)) else w.shape[1]
 
 
 def _stream():
@@ -76,7 +95,8 @@ _TUNE = None
 _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1), (17, 2), (16, 2), (17, 8), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1),
                # round 3 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups; refused for f32 / NCTHW outputs)
                (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (21, 2), (21, 4), (21, 8), (22, 2), (22, 4),
-               (23, 2), (24, 2), (24, 4), (25, 2), (25, 4), (25, 8), (26, 2), (26, 4), (27, 2), (27, 4), (28, 2), (28, 4), (28, 8), (29, 2)]
+               (23, 2), (24, 2), (24, 4), (25, 2), (25, 4), (25, 8), (26, 2), (26, 4), (27, 2), (27, 4), (28, 2), (28, 4), (28, 8), (29, 2),
+               (31, 1), (33, 1), (34, 1), (35, 1), (39, 1), (31, 2), (31, 4), (31, 8), (33, 2), (33, 4), (34, 2), (34, 4), (35, 2), (35, 4), (35, 8)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
 # GEMM epilogues can emit the next GroupNorm's column sums (gn_stats=True call sites). OFF by default: measured on MI355X the fused
 # path is correct but not faster yet (round 2: -3.5 % bf16x3, -7 % bf16 with the first finalize kernel) - the epilogue work lands on
@@ -127,6 +147,7 @@ def workspace(device):
     if ws is None:
         ws = _WS[device] = (torch.empty(WORKSPACE_BYTES, device=device, dtype=torch.uint8),
                             torch.zeros(256, device=device, dtype=torch.uint8))
+        gn_barrier(device)      # allocated with the other persistent scratch, i.e. never inside a graph capture
     return ws
 
 
@@ -139,7 +160,12 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     lib = _lib.load()
     _dev(a, "A"); _dev(w, "W"); _dev(out, "out")
     a_split, w_split = is_split(a, w), is_split(w, a)
-    if a_split or w_split:
+    if isinstance(a, SplitAct) or isinstance(w, SplitAct):     # pre-split activations x pre-split weights (bf16 storage, 4 bytes per K element)
+        assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and lda % 2 == 0 and ldw % 2 == 0 and a_bs % 2 == 0 and w_bs % 2 == 0
+        a_split = w_split = True
+        code = BF16X3
+        lda, a_bs, ldw, w_bs = lda // 2, a_bs // 2, ldw // 2, w_bs // 2
+    elif a_split or w_split:
         code = BF16X3
         if a_split:
             assert lda % 2 == 0 and a_bs % 2 == 0
@@ -173,6 +199,10 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.alpha, p.split_k = alpha, split_k
     p.debug_ablate = DEBUG_ABLATE
     p.a_split, p.w_split = int(a_split), int(w_split)
+    p.o_split = int(isinstance(out, SplitAct))
+    if p.o_split:
+        assert code == BF16X3 and ldo % 2 == 0 and o_bs % 2 == 0
+        p.ldo, p.o_bs, p.out_dtype = ldo // 2, o_bs // 2, F32
     p.gn_colsum = 0
     ws, zeros = workspace(a.device)
     p.workspace, p.workspace_bytes, p.zeros = ws.data_ptr(), ws.numel(), zeros.data_ptr()
@@ -184,8 +214,12 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     if tile_hint == 0 and split_k == 0:
         key = f"{p.dtype}/{p.out_dtype}|{M}x{N}x{K}|c{Cin}|t{KT}{KH}{KW}s{stride}u{ups}|a{act}r{int(residual is not None)}n{int(out_nchw)}|b{batch}"
         if code == BF16X3:
-            key += f"|x{int(a_split)}{int(w_split)}"
+            key += f"|x{int(a_split)}{int(w_split)}" + ("o" if p.o_split else "")
         cfg = _tune_table().get(key)
+        if cfg is None and code == BF16X3 and a_split and w_split:
+            # pre-split activations: same tile geometry as the raw-activation launch of the same shape (table measured on those)
+            base = key.split("|x")[0]
+            cfg = _tune_table().get(base + "|x01") or _tune_table().get(base + "|x10")
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
@@ -210,13 +244,20 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     return out
 
 
-def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0, split_k=0, gn_stats=False):
-    """x [M, K] (row pitch free), w packed [N, K]; GEGLU (act=2) returns [M, N/2]."""
-    M, K = x.shape
+def _out_dtype(x, out_dtype):
+    return out_dtype or (torch.float32 if isinstance(x, SplitAct) else x.dtype)
+
+
+def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0, split_k=0, gn_stats=False,
+           split_out=False):
+    """x [M, K] (row pitch free), w packed [N, K]; GEGLU (act=2) returns [M, N/2]. `split_out` (bf16x3): the result is written as a
+    SplitAct (the next GEMM's pre-split A operand)."""
+    M, K = x.shape[0], act_k(x)
     N = w.shape[0]
     assert kdim(w, x) == K, (w.shape, x.shape)
     if out is None:
-        out = torch.empty((M, N // 2 if act == 2 else N), device=x.device, dtype=out_dtype or x.dtype)
+        nout = N // 2 if act == 2 else N
+        out = new_split(M, nout, x.device) if split_out else torch.empty((M, nout), device=x.device, dtype=_out_dtype(x, out_dtype))
     return conv_gemm(x, w, out, M=M, N=N, K=K, Cin=K, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), bias=bias,
                      residual=residual, ldr=_ld(residual) if residual is not None else 0, act=act, alpha=alpha,
                      tile_hint=tile_hint, split_k=split_k, gn_stats=gn_stats)
@@ -228,7 +269,7 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1
     [B, C, T, Hout, Wout] tensor (`out` may be a channel-offset view of a wider tensor with `nchw_channels` channels).
     `pad_end` = extra zero rows / columns at the bottom / right only (ae_modules.py:102-106 pads (0,1,0,1) before its
     stride-2 conv): the gather treats every out-of-image tap as zero, so only the output size changes."""
-    Cin = x.shape[1]
+    Cin = act_k(x)
     N = w.shape[0]
     Hs, Ws = Hin * ups, Win * ups
     Hout = (Hs + 2 * pad + pad_end - KH) // stride + 1
@@ -240,7 +281,7 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1
         if out_nchw:
             out = torch.empty((F // T, N, T, Hout, Wout), device=x.device, dtype=out_dtype or torch.float32)
         else:
-            out = torch.empty((M, N), device=x.device, dtype=out_dtype or x.dtype)
+            out = torch.empty((M, N), device=x.device, dtype=_out_dtype(x, out_dtype))
     conv_gemm(x, w, out, M=M, N=N, K=KH * KW * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=(nchw_channels or N) if out_nchw else _ld(out), T=T,
               Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=KH, KW=KW, ph=pad, pw=pad, stride=stride, ups=ups, bias=bias,
               rowbias=rowbias, rowbias_div=rowbias_div, residual=residual,
@@ -251,12 +292,12 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1
 
 def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None, gn_stats=False, tile_hint=0, split_k=0):
     """nn.Conv3d kernel (3,1,1), padding (1,0,0) on tokens [(b t) hw, C]; w packed [N, 3*C]."""
-    Cin = x.shape[1]
+    Cin = act_k(x)
     N = w.shape[0]
     M = B * T * HW
     assert x.shape[0] == M and kdim(w, x) == 3 * Cin
     if out is None:
-        out = torch.empty((M, N), device=x.device, dtype=x.dtype)
+        out = torch.empty((M, N), device=x.device, dtype=_out_dtype(x, None))
     return conv_gemm(x, w, out, M=M, N=N, K=3 * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), T=T, Hin=HW, Win=1,
                      Hout=HW, Wout=1, KT=3, pt=1, bias=bias, residual=residual,
                      ldr=_ld(residual) if residual is not None else 0, gn_stats=gn_stats, tile_hint=tile_hint, split_k=split_k)
@@ -272,20 +313,38 @@ def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias
 _gn_ws = {}
 
 
-def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=False, out=None):
+GN_ONE_LAUNCH = _os.environ.get("GEO4D_GN_ONE_LAUNCH", "1") != "0"   # statistics + merge + apply around a grid-wide barrier (norm.hip)
+_gn_barrier = {}
+
+
+def gn_barrier(device):
+    """8 zero bytes per device for the one-launch GroupNorm's grid barrier (self-resetting; GroupNorms are stream-ordered).
+    Allocated on first use outside graph capture (callers warm up eagerly before capturing)."""
+    b = _gn_barrier.get(device)
+    if b is None:
+        b = _gn_barrier[device] = torch.zeros(2, device=device, dtype=torch.int32)
+    return b
+
+
+def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=False, out=None, split_out=False):
+    """`split_out` (f32 input of the bf16x3 mode): y is returned as a SplitAct, the pre-split A operand of the conv that follows."""
     lib = _lib.load()
     _dev(x, "x")
+    assert not isinstance(x, SplitAct), "GroupNorm reads plain activations"
     Cc = x.shape[1]
     assert x.shape[0] == F * HW, (x.shape, F, HW)
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
     if out is None:
-        out = torch.empty((F * HW, Cc), device=x.device, dtype=x.dtype)
+        out = new_split(F * HW, Cc, x.device) if split_out else torch.empty((F * HW, Cc), device=x.device, dtype=x.dtype)
+    split_out = isinstance(out, SplitAct)
     need = lib.geo4d_groupnorm_workspace(F, HW, groups, frames_per_stat)
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     p = GroupNorm()
     p.x, p.y, p.gamma, p.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
     p.workspace, p.workspace_bytes = ws.data_ptr(), need
-    p.ldx, p.ldy = _ld(x), _ld(out)
+    p.ldx, p.ldy = _ld(x), (_ld(out) // 2 if split_out else _ld(out))
+    p.split_out = int(split_out)
+    p.barrier = gn_barrier(x.device).data_ptr() if GN_ONE_LAUNCH else 0
     p.F, p.HW, p.C, p.groups, p.frames_per_stat = F, HW, Cc, groups, frames_per_stat
     p.act, p.dtype, p.eps = int(silu), dt_code(x.dtype), eps
     cs = getattr(x, "_gn_colsum", None)     # column sums left on this very tensor object by the GEMM that produced it
@@ -294,10 +353,18 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5, out=None):
+def layernorm(x, gamma, beta, eps=1e-5, out=None, split_out=False):
     lib = _lib.load()
     _dev(x, "x")
+    assert not isinstance(x, SplitAct), "LayerNorm reads plain activations"
     M, Cc = x.shape
+    if split_out or isinstance(out, SplitAct):
+        assert x.dtype == torch.float32
+        if out is None:
+            out = new_split(M, Cc, x.device)
+        _lib.check(lib.geo4d_layernorm_split(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out) // 2, M, Cc, eps, gamma.data_ptr(),
+                                             beta.data_ptr(), _stream()), "geo4d_layernorm_split")
+        return out
     if out is None:
         out = torch.empty((M, Cc), device=x.device, dtype=x.dtype)
     _lib.check(lib.geo4d_layernorm(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), M, Cc, eps, gamma.data_ptr(),
@@ -326,15 +393,17 @@ def softmax_rows(x, scale, out_dtype, out=None, causal_period=0):
 ATTN_VARIANT = int(_os.environ.get("GEO4D_ATTN_VARIANT", "0"))   # 0 = library default; 1..3 = A/B builds (include/geo4d_hip.h)
 
 
-def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False, variant=None):
+def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False, variant=None, split_out=False):
     """q [B*Nq, >=H*64] view; kv = list of (k, vt, Nk, kv_div, vt_bs): k [(B/kv_div)*Nk, >=H*64] view, vt = V TRANSPOSED
     as a [>=H*64, ld] view (row = channel, column = key) whose batch b' starts vt_bs elements after batch b'-1."""
     lib = _lib.load()
     _dev(q, "q")
     if out is None:
-        out = torch.empty((B * Nq, H * 64), device=q.device, dtype=q.dtype)
+        out = new_split(B * Nq, H * 64, q.device) if split_out else torch.empty((B * Nq, H * 64), device=q.device, dtype=q.dtype)
+    split_out = isinstance(out, SplitAct)
     p = Attention()
-    p.q, p.o, p.ldq, p.ldo = q.data_ptr(), out.data_ptr(), _ld(q), _ld(out)
+    p.q, p.o, p.ldq, p.ldo = q.data_ptr(), out.data_ptr(), _ld(q), (_ld(out) // 2 if split_out else _ld(out))
+    p.split_out = int(split_out)
     assert 1 <= len(kv) <= 2
     for i, (k, vt, nk, div, vt_bs) in enumerate(kv):
         assert k.dtype == q.dtype and vt.dtype == q.dtype
@@ -354,9 +423,10 @@ def linear_t_batched(w, x, batch, rows, dtype_align=None):
     """Per-batch operand-swapped projection: x [batch*rows, K] -> out [batch, N, rows_pad] with out[b, n, m] =
     sum_k w[n, k] x[b*rows + m, k]; rows_pad = rows rounded up to a 16-byte multiple (zero filled). This is V^T per frame."""
     N, K = w.shape[0], kdim(w, x)
-    epc = 4 if x.dtype == torch.float32 else 8
+    odt = _out_dtype(x, None)
+    epc = 4 if odt == torch.float32 else 8
     rp = (rows + epc - 1) // epc * epc
-    out = (torch.zeros if rp != rows else torch.empty)((batch, N, rp), device=x.device, dtype=x.dtype)
+    out = (torch.zeros if rp != rows else torch.empty)((batch, N, rp), device=x.device, dtype=odt)
     conv_gemm(w, x, out, M=N, N=rows, K=K, Cin=K, lda=_ld(w), ldw=_ld(x), ldo=rp, batch=batch, a_bs=0, w_bs=rows * _ld(x), o_bs=N * rp)
     return out, rp
 
@@ -368,18 +438,20 @@ def linear_t(w, x, bias=None, *, out=None, pad_cols=None):
     M = x.shape[0]
     if out is None:
         cols = pad_cols or M
-        out = torch.zeros((N, cols), device=x.device, dtype=x.dtype) if cols != M else torch.empty((N, M), device=x.device, dtype=x.dtype)
+        odt = _out_dtype(x, None)
+        out = torch.zeros((N, cols), device=x.device, dtype=odt) if cols != M else torch.empty((N, M), device=x.device, dtype=odt)
     return conv_gemm(w, x, out, M=N, N=M, K=K, Cin=K, lda=_ld(w), ldw=_ld(x), ldo=_ld(out), bias=bias, bias_per_row=True)
 
 
-def temporal_attention(q, k, v, *, B, T, HW, H, scale, out=None):
+def temporal_attention(q, k, v, *, B, T, HW, H, scale, out=None, split_out=False):
     lib = _lib.load()
     _dev(q, "q")
     if out is None:
-        out = torch.empty((B * T * HW, H * 64), device=q.device, dtype=q.dtype)
-    _lib.check(lib.geo4d_temporal_attention(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(),
-                                            _ld(out), B, T, HW, H, 64, scale, dt_code(q.dtype), _stream()),
-               "geo4d_temporal_attention")
+        out = new_split(B * T * HW, H * 64, q.device) if split_out else torch.empty((B * T * HW, H * 64), device=q.device, dtype=q.dtype)
+    split_out = isinstance(out, SplitAct)
+    _lib.check(lib.geo4d_temporal_attention2(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(),
+                                             _ld(out) // 2 if split_out else _ld(out), B, T, HW, H, 64, scale, dt_code(q.dtype),
+                                             int(split_out), _stream()), "geo4d_temporal_attention")
     return out
 
 

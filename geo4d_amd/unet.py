@@ -164,6 +164,9 @@ def layer_shapes(add, L, c):
         add(p + ".conv.weight", (L.cout, L.cin, 3, 3)); add(p + ".conv.bias", (L.cout,))
 
 
+PRESPLIT = os.environ.get("GEO4D_X3_PRESPLIT", "1") != "0"
+
+
 # ------------------------------------------------------------------------------------------------------
 class UNetModel(ParamTree):
     def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
@@ -238,6 +241,12 @@ class UNetModel(ParamTree):
         self.compute_dtype = resolve_dtype(d)
         self.invalidate()
         return self
+
+    @property
+    def presplit(self):
+        """bf16x3: producers whose only consumers are GEMMs (GroupNorm / LayerNorm / attention / GEGLU epilogue) write the pre-split
+        operand format, so conv_gemm's K loop does not split activation fragments (measured: 12-29 % of a GEMM's time)."""
+        return bool(self.compute_dtype.x3) and PRESPLIT
 
     @property
     def storage_dtype(self):
@@ -391,42 +400,45 @@ class UNetModel(ParamTree):
     # ---- layer executors (all enqueue HIP kernels; tensors are token matrices [(b t) hw, C]) -------------
     def _res(self, e, L, h, emb_all, B, T, H, W):
         F_, HW = B * T, H * W
-        a = ops.groupnorm(h, *e["gn1"], F=F_, HW=HW, eps=1e-5, silu=True)
+        sp = self.presplit
+        a = ops.groupnorm(h, *e["gn1"], F=F_, HW=HW, eps=1e-5, silu=True, split_out=sp)
         lo, hi = e["emb"]
         h1, _, _ = ops.conv2d(a, e["w1"], e["b1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, rowbias=emb_all[:, lo:hi],
                               rowbias_div=T * HW, gn_stats=True)      # gn_stats: the epilogue sums the next GroupNorm's statistics
-        a = ops.groupnorm(h1, *e["gn2"], F=F_, HW=HW, eps=1e-5, silu=True)
+        a = ops.groupnorm(h1, *e["gn2"], F=F_, HW=HW, eps=1e-5, silu=True, split_out=sp)
         skip = ops.linear(h, *e["skip"]) if "skip" in e else h
         h2, _, _ = ops.conv2d(a, e["w2"], e["b2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True)
         if "tc" in e:
             y = h2
             for i, (gn, w, b) in enumerate(e["tc"]):
-                a = ops.groupnorm(y, *gn, F=F_, HW=HW, eps=1e-5, frames_per_stat=T, silu=True)
+                a = ops.groupnorm(y, *gn, F=F_, HW=HW, eps=1e-5, frames_per_stat=T, silu=True, split_out=sp)
                 y = ops.conv_temporal(a, w, b, B=B, T=T, HW=HW, residual=h2 if i == 3 else None, gn_stats=True)
             h2 = y
         return h2
 
     def _ff(self, blk, x):
-        g = ops.linear(ops.layernorm(x, *blk["norm3"]), *blk["ff1"], act=2)
+        sp = self.presplit
+        g = ops.linear(ops.layernorm(x, *blk["norm3"], split_out=sp), *blk["ff1"], act=2, split_out=sp)
         return ops.linear(g, *blk["ff2"], residual=x)
 
     def _spatial(self, e, L, h, kv, B, T, H, W):
         F_, N, C_, heads = B * T, H * W, L.inner, L.heads
         blk = e["blk"]
-        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=N, eps=1e-6), *e["in"])
-        n1 = ops.layernorm(x, *blk["norm1"])
+        sp = self.presplit
+        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=N, eps=1e-6, split_out=sp), *e["in"])
+        n1 = ops.layernorm(x, *blk["norm1"], split_out=sp)
         qk = ops.linear(n1, blk["attn1.qk"])
         vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
         x3 = self.compute_dtype.x3
-        att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3)
+        att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn1.o"], residual=x)
-        q = ops.linear(ops.layernorm(x, *blk["norm2"]), blk["attn2.q"])
+        q = ops.linear(ops.layernorm(x, *blk["norm2"], split_out=sp), blk["attn2.q"])
         k_t, k_i, vt_t, vt_i, _ = kv
         off, _ = e["kv"]
         sets = [(k_t[:, off:off + C_], vt_t[L.prefix].reshape(-1, 80), 77, T, C_ * 80)]
         if k_i is not None:
             sets.append((k_i[:, off:off + C_], vt_i[L.prefix], 16, 1, 16))
-        att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3)
+        att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
         x = self._ff(blk, x)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)
@@ -434,10 +446,11 @@ class UNetModel(ParamTree):
     def _temporal(self, e, L, h, B, T, H, W):
         F_, HW, C_, heads = B * T, H * W, L.inner, L.heads
         blk = e["blk"]
-        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=HW, eps=1e-6, frames_per_stat=T), *e["in"])
+        sp = self.presplit
+        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=HW, eps=1e-6, frames_per_stat=T, split_out=sp), *e["in"])
         for a, n in (("attn1", "norm1"), ("attn2", "norm2")):
-            qkv = ops.linear(ops.layernorm(x, *blk[n]), blk[a + ".qkv"])
-            att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125)
+            qkv = ops.linear(ops.layernorm(x, *blk[n], split_out=sp), blk[a + ".qkv"])
+            att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125, split_out=sp)
             x = ops.linear(att, *blk[a + ".o"], residual=x)
         x = self._ff(blk, x)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)
@@ -502,7 +515,7 @@ class UNetModel(ParamTree):
             s, sh, sw = hs.pop()
             assert (sh, sw) == (H, W), "latent height/width must be multiples of 8"
             h, H, W = self._run(P, blk, ops.concat_channels(h, s), emb_all, kv, B, T, H, W)
-        a = ops.groupnorm(h, *P["out_gn"], F=B * T, HW=H * W, eps=1e-5, silu=True)
+        a = ops.groupnorm(h, *P["out_gn"], F=B * T, HW=H * W, eps=1e-5, silu=True, split_out=self.presplit)
         y, _, _ = ops.conv2d(a, P["out_w"], P["out_b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, T=T, out_nchw=True,
                              out_dtype=torch.float32)
         return y if x.dtype == torch.float32 else y.to(x.dtype)

@@ -227,10 +227,17 @@ class AutoencoderKL(ParamTree):
         return P
 
     # ---- kernels -------------------------------------------------------------------------------------------------
+    @property
+    def presplit(self):
+        """bf16x3: GroupNorm outputs that only feed a conv are written in conv_gemm's pre-split operand format (see unet.py)."""
+        from .unet import PRESPLIT
+        return bool(self.compute_dtype.x3) and PRESPLIT
+
     def _resnet(self, e, x, F_, H, W):
-        a = ops.groupnorm(x, *e["gn1"], F=F_, HW=H * W, eps=1e-6, silu=True)
+        sp = self.presplit
+        a = ops.groupnorm(x, *e["gn1"], F=F_, HW=H * W, eps=1e-6, silu=True, split_out=sp)
         h, _, _ = ops.conv2d(a, *e["c1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True)
-        a = ops.groupnorm(h, *e["gn2"], F=F_, HW=H * W, eps=1e-6, silu=True)
+        a = ops.groupnorm(h, *e["gn2"], F=F_, HW=H * W, eps=1e-6, silu=True, split_out=sp)
         skip = ops.linear(x, *e["nin"]) if "nin" in e else x
         out, _, _ = ops.conv2d(a, *e["c2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True)
         return out
@@ -289,7 +296,7 @@ class AutoencoderKL(ParamTree):
 
     def _head(self, head, feat, F_, H, W, out, T, nchw_channels):
         gn, w, b = head
-        a = ops.groupnorm(feat, *gn, F=F_, HW=H * W, eps=1e-6, silu=True)
+        a = ops.groupnorm(feat, *gn, F=F_, HW=H * W, eps=1e-6, silu=True, split_out=self.presplit)
         ops.conv2d(a, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, T=T, out=out, out_nchw=True, nchw_channels=nchw_channels)
 
     def _conf(self, P, feat, F_, H, W):
@@ -338,7 +345,7 @@ class AutoencoderKL(ParamTree):
             for e in P["enc_adaptor"]:
                 h = self._resnet(e, h, n, H, W)
             gn, w, b = P["enc_adaptor_head"]
-            a = ops.groupnorm(h, *gn, F=n, HW=H * W, eps=1e-6, silu=True)
+            a = ops.groupnorm(h, *gn, F=n, HW=H * W, eps=1e-6, silu=True, split_out=self.presplit)
             t, _, _ = ops.conv2d(a, w, b, F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=t)
         h, _, _ = ops.conv2d(t, *P["enc_in"], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1)
         for kind, e in P["enc"]:

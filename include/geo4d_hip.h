@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEO4D_ABI_VERSION 3
+#define GEO4D_ABI_VERSION 4
 
 /* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
  * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
@@ -63,13 +63,19 @@ typedef struct geo4d_conv_gemm_t {
                             GEGLU on 16 / 17. Round 3, bf16 / f16 / bf16x3 only (16x16x32 MFMA, register epilogue, persistent
                             workgroups; no NCTHW output, no gn_colsum): 21 = 256x128, 22 = 256x256, 23 = 160x320 (8 waves,
                             80x80 wave tiles), 24 = 160x160 (4 waves), 25 = 128x128, 26 = 128x64, 27 = 64x128, 28 = 64x64,
-                            29 = 128x256; GEGLU on 21, 22, 25, 27, 29. Others: -EINVAL */
+                            29 = 128x256; the same with THREE activation-panel
+                            buffers (the A panel two K slabs ahead): 31 = 256x128, 33 = 160x320, 34 = 160x160, 35 = 128x128,
+                            39 = 128x256; GEGLU on 21, 22, 25, 27, 29, 31, 35, 39. Others: -EINVAL */
     int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
     int debug_ablate;    /* 0 in production. 1 (bf16x3 profiling only): skip the in-register hi/lo split -> WRONG results;
                             2 (tests only, tile hints >= 21): launch 3 persistent workgroups whatever the problem size */
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */
+    int o_split;         /* dtype 3 (bf16x3), out_dtype F32 only: O is written in the pre-split operand format ([8 x bf16 hi | 8 x bf16 lo]
+                            per 8 output columns; ldo / o_bs still count columns) - the producer side of a_split for GEMM chains
+                            (GEGLU -> FF out). Needs the vector epilogue (stored columns % 8 == 0, aligned rows), no residual,
+                            row-major output, no gn_colsum */
     float* gn_colsum;    /* optional [M/32][N][2] fp32: per 32-row block and output column, (sum, sum of squares) of the values this
                             launch stores - the statistics pass of the GroupNorm that consumes O, produced for free by the epilogue
                             (geo4d_groupnorm_t.colsum). Needs M % 32 == 0, N % 8 == 0, row-major 16-byte aligned output, batch 1,
@@ -91,6 +97,11 @@ typedef struct geo4d_groupnorm_t {
     float eps;
     const float* colsum; /* optional: [F*HW/32][C][2] column sums written by the producing geo4d_conv_gemm (gn_colsum); when given
                             (needs HW % 32 == 0) the pass over x that computes the statistics is skipped */
+    void* barrier;       /* optional: 8 bytes of persistent, zero-initialised device memory (one GroupNorm at a time per buffer, i.e.
+                            stream-ordered use). When given and every workgroup can be resident, statistics + merge + apply run as ONE
+                            launch around a grid-wide barrier (bit-identical to the three-launch path); NULL = three launches */
+    int split_out;       /* bf16x3 producers (dtype F32 only, C % 8 == 0): y is written in the PRE-SPLIT operand format of
+                            geo4d_conv_gemm_t.a_split - per 8 channels [8 x bf16 hi | 8 x bf16 lo]; ldy still counts channels */
 } geo4d_groupnorm_t;
 size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat);
 int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);
@@ -98,6 +109,10 @@ int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);
 /* LayerNorm over the last dim; replaces nn.LayerNorm (attention.py:225-227). */
 int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
                     const float* beta, int dtype, void* stream);
+
+/* the same for an f32 x, writing y in the pre-split bf16x3 operand format (see geo4d_groupnorm_t.split_out); C % 8 == 0. */
+int geo4d_layernorm_split(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
+                          const float* beta, void* stream);
 
 /* y = softmax(scale * x) per row, x fp32; replaces F.softmax in the VAE AttnBlock (ae_modules.py:66-68). */
 int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,
@@ -121,6 +136,8 @@ typedef struct geo4d_attention_t {
     int Nk[2], kv_div[2];
     int B, H, Nq, nseg, head_dim, dtype;
     float scale;
+    int split_out;       /* dtype 3 (bf16x3) only: o is written in the pre-split operand format of geo4d_conv_gemm_t.a_split (ldo still
+                            counts channels) - the to_out projection consumes it without splitting again */
     int variant;         /* 0 = default; A/B builds of the same math: 1 = 128 query rows per workgroup, 2 = the same compiled for
                             4 waves per SIMD (16-bit types), 3 = 256 rows per workgroup, two query blocks per wave (nseg == 1) */
 } geo4d_attention_t;
@@ -130,6 +147,9 @@ int geo4d_attention(const geo4d_attention_t* p, void* stream);
  * replaces the einsum/softmax path of CrossAttention inside TemporalTransformer (attention.py:101-125, 365-412). */
 int geo4d_temporal_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                              int B, int T, int HW, int H, int head_dim, float scale, int dtype, void* stream);
+/* the same with `split_out` (dtype 3 = bf16x3 only): o in the pre-split operand format, see geo4d_attention_t.split_out */
+int geo4d_temporal_attention2(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                              int B, int T, int HW, int H, int head_dim, float scale, int dtype, int split_out, void* stream);
 
 /* [B,C0,T,H,W] (+ [B,C1,T,H,W]) fp32 -> tokens [(b t) hw][Cpad] (zero padded);
  * replaces torch.cat([x] + c_concat, 1) + rearrange (ddpm3d.py:2540-2544; openaimodel3d.py:588). */

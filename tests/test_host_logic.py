@@ -128,7 +128,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.geo4d_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define GEO4D_ABI_VERSION (\d+)", hdr).group(1))
-    assert ctypes.sizeof(_lib.ConvGemm) == 9 * 8 + 9 * 8 + 27 * 4 + 4 + 2 * 4 + 8, ctypes.sizeof(_lib.ConvGemm)   # + gn_colsum
+    assert ctypes.sizeof(_lib.ConvGemm) == 9 * 8 + 9 * 8 + 27 * 4 + 4 + 3 * 4 + 4 + 8, ctypes.sizeof(_lib.ConvGemm)   # + o_split (+ pad), gn_colsum
     assert lib.geo4d_groupnorm_workspace(16, 2560, 32, 1) == (16 * 64 * 32 * 3 + 16 * 32 * 2) * 4
     # argument validation happens on the host before any launch: bad descriptors return -EINVAL with a message
     p = _lib.ConvGemm()
@@ -144,13 +144,13 @@ def test_tuning_table_uses_only_known_tile_hints():
     here = os.path.dirname(os.path.abspath(ops.__file__))
     table = json.load(open(os.path.join(here, "tuning", "gfx950.json")))
     header = open(os.path.join(os.path.dirname(here), "include", "geo4d_hip.h")).read()
-    documented = {0, 1, 2, 3, 4, 5} | {int(x) for x in re.findall(r"\b(1[1-9]) = \d+x\d+", header)}
+    documented = {0, 1, 2, 3, 4, 5} | {int(x) for x in re.findall(r"\b([123][0-9]) = \d+x\d+", header)}
     assert {11, 13, 16} <= documented
     assert len(table) > 100
     for key, (tile, split) in table.items():
         assert tile in documented, (key, tile)
         assert split in (0, 1, 2, 4, 8, 16), (key, split)
-        assert re.match(r"^\d/\d\|\d+x\d+x\d+\|c\d+\|t\d{3}s\du\d\|a\dr\dn\d\|b\d+(\|x[01][01])?$", key), key   # |xAW: bf16x3 pre-split operand flags
+        assert re.match(r"^\d/\d\|\d+x\d+x\d+\|c\d+\|t\d{3}s\du\d\|a\dr\dn\d\|b\d+(\|x[01][01]o?)?$", key), key   # |xAW: bf16x3 pre-split operand flags
     assert all(t in documented for t, _ in ops._CANDIDATES)
 
 

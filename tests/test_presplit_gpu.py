@@ -1,0 +1,183 @@
+"""bf16x3 producer / consumer chain in the PRE-SPLIT operand format (round 3) and the one-launch GroupNorm.
+
+Producers (GroupNorm, LayerNorm, both attention kernels, the GEGLU epilogue) can write their f32 result as [8 x bf16 hi | 8 x bf16 lo]
+per 8 channels (ops.SplitAct); conv_gemm then multiplies it without splitting fragments in its K loop. Checked here:
+  * every producer's split output decodes (hi + lo) to its own plain f32 output within bf16x3 resolution, and hi is exactly bf16(f32);
+  * conv_gemm on a SplitAct A operand (linear / 3x3 conv with gather + zero padding / temporal conv / operand-swapped V^T projection)
+    equals conv_gemm on the same values given as raw f32 BIT FOR BIT (the split happens before the MFMA either way), on first- and
+    second-generation tiles;
+  * GroupNorm in one launch (grid barrier) == GroupNorm in three launches bit for bit, 4-D and 5-D statistics, and when repeated."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def decode_split(t):
+    """SplitAct [M, 2K] bf16 -> (hi, lo) as f32 [M, K]."""
+    m, k2 = t.shape
+    v = t.as_subclass(torch.Tensor).reshape(m, k2 // 16, 2, 8).float()
+    return v[:, :, 0].reshape(m, k2 // 2), v[:, :, 1].reshape(m, k2 // 2)
+
+
+def check_split(name, split, plain):
+    hi, lo = decode_split(split)
+    assert torch.equal(hi, plain.to(torch.bfloat16).float()), f"{name}: hi is not bf16(value)"
+    err = ((hi + lo - plain).norm() / plain.norm()).item()
+    print(f"[{name}] split decode rel_l2 = {err:.3e}")
+    assert err < 2e-5
+
+
+def make_split(x):
+    """Host-side reference packer (pack.split_bf16 is the weight-side twin)."""
+    from geo4d_amd import ops, pack
+    return ops.SplitAct.wrap(pack.split_bf16(x))
+
+
+@pytest.mark.parametrize("case", [(4, 6 * 7, 320, 1, True), (6, 5 * 4, 64, 3, False), (2, 70 * 33, 128, 1, True), (16, 160, 1280, 16, True)])
+def test_groupnorm_split_output_and_one_launch(dev, case):
+    from geo4d_amd import ops
+    F, HW, C, fps, silu = case
+    x = rnd((F * HW, C), dev, 1) * 2 + 0.5
+    g, b = rnd((C,), dev, 2) + 1, rnd((C,), dev, 3)
+    ops.GN_ONE_LAUNCH = False
+    try:
+        y3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
+        s3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
+    finally:
+        ops.GN_ONE_LAUNCH = True
+    y1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
+    y1b = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)          # the barrier resets itself
+    s1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
+    assert torch.equal(y1, y3) and torch.equal(y1, y1b), "one-launch GroupNorm differs from the three-launch path"
+    assert torch.equal(s1.as_subclass(torch.Tensor), s3.as_subclass(torch.Tensor))
+    ref = TF.group_norm(x.reshape(F // fps, fps * HW, C).permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1).reshape(F * HW, C)
+    if silu:
+        ref = TF.silu(ref)
+    assert ((y1 - ref).norm() / ref.norm()).item() < 2e-5
+    check_split(f"groupnorm {case}", s1, y1)
+
+
+def test_groupnorm_one_launch_many_in_a_row_and_big_grid(dev):
+    """Back-to-back one-launch GroupNorms on one stream share the barrier words; a tensor whose default chunking exceeds the resident
+    workgroup count takes longer chunks (VAE-sized: 48 frames x 40x64 x 512 channels)."""
+    from geo4d_amd import ops
+    F, HW, C = 48, 2560, 512
+    x = rnd((F * HW, C), dev, 5)
+    g, b = rnd((C,), dev, 6) + 1, rnd((C,), dev, 7)
+    outs = [ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-6, silu=True) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = TF.silu(TF.group_norm(x.reshape(F, HW, C).permute(0, 2, 1), 32, g, b, 1e-6).permute(0, 2, 1).reshape(F * HW, C))
+    assert ((outs[0] - ref).norm() / ref.norm()).item() < 2e-5
+
+
+@pytest.mark.parametrize("C", [320, 640, 1280, 512])
+def test_layernorm_split(dev, C):
+    from geo4d_amd import ops
+    x = rnd((777, C), dev, 10) * 3
+    g, b = rnd((C,), dev, 11) + 1, rnd((C,), dev, 12)
+    check_split(f"layernorm {C}", ops.layernorm(x, g, b, split_out=True), ops.layernorm(x, g, b))
+
+
+def test_attention_kernels_split_output(dev):
+    from geo4d_amd import ops
+    B, H, N = 2, 5, 200
+    C_ = H * 64
+    qkv = rnd((B * N, 3 * C_), dev, 20)
+    Np = (N + 3) // 4 * 4
+    vt = torch.zeros((B, C_, Np), device=dev)
+    vt[:, :, :N] = qkv[:, 2 * C_:].reshape(B, N, C_).permute(0, 2, 1)
+    kv = [(qkv[:, C_:2 * C_], vt.reshape(-1, Np), N, 1, C_ * Np)]
+    for x3 in (True, False):
+        plain = ops.attention(qkv[:, :C_], kv, B=B, H=H, Nq=N, scale=0.125, x3=x3)
+        check_split(f"flash x3={x3}", ops.attention(qkv[:, :C_], kv, B=B, H=H, Nq=N, scale=0.125, x3=x3, split_out=True), plain)
+    Bt, T, HW = 1, 16, 37
+    q3 = rnd((Bt * T * HW, 3 * C_), dev, 21)
+    plain = ops.temporal_attention(q3[:, :C_], q3[:, C_:2 * C_], q3[:, 2 * C_:], B=Bt, T=T, HW=HW, H=H, scale=0.125)
+    check_split("temporal", ops.temporal_attention(q3[:, :C_], q3[:, C_:2 * C_], q3[:, 2 * C_:], B=Bt, T=T, HW=HW, H=H, scale=0.125, split_out=True), plain)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 11, 13, 16, 17, 21, 22, 23, 25, 28, 31, 33])
+def test_gemm_on_presplit_activations_equals_raw(dev, tile):
+    from geo4d_amd import ops, pack
+    M, K, N = 1000, 320, 456
+    x, w, b = rnd((M, K), dev, 30), rnd((N, K), dev, 31, 0.05), rnd((N,), dev, 32)
+    r = rnd((M, N), dev, 33)
+    wp = pack.pack_linear(w, "bf16x3")
+    raw = ops.linear(x, wp, b, residual=r, tile_hint=tile)
+    pre = ops.linear(make_split(x), wp, b, residual=r, tile_hint=tile)
+    assert pre.dtype == torch.float32 and torch.equal(raw, pre), f"tile {tile}: {((raw - pre).norm() / raw.norm()).item():.3e}"
+    assert ((raw - (x @ w.t() + b + r)).norm() / raw.norm()).item() < 3e-5
+    # 3x3 conv: gather + zero padding + stride on split rows
+    F, H, W, Ci, Co = 3, 12, 9, 64, 96
+    xc = rnd((F * H * W, Ci), dev, 34)
+    wc, bc = pack.pack_conv2d(rnd((Co, Ci, 3, 3), dev, 35, 0.05), "bf16x3"), rnd((Co,), dev, 36)
+    for stride, ups in ((1, 1), (2, 1), (1, 2)):
+        a = ops.conv2d(xc, wc, bc, F=F, Hin=H, Win=W, KH=3, KW=3, stride=stride, pad=1, ups=ups, tile_hint=tile)[0]
+        c = ops.conv2d(make_split(xc), wc, bc, F=F, Hin=H, Win=W, KH=3, KW=3, stride=stride, pad=1, ups=ups, tile_hint=tile)[0]
+        assert torch.equal(a, c), f"conv tile {tile} stride {stride} ups {ups}"
+    # temporal conv
+    Bt, T, HW, Cc = 2, 7, 45, 128
+    xt = rnd((Bt * T * HW, Cc), dev, 37)
+    wt, bt = pack.pack_conv3d_t(rnd((Cc, Cc, 3, 1, 1), dev, 38, 0.05), "bf16x3"), rnd((Cc,), dev, 39)
+    assert torch.equal(ops.conv_temporal(xt, wt, bt, B=Bt, T=T, HW=HW, tile_hint=tile),
+                       ops.conv_temporal(make_split(xt), wt, bt, B=Bt, T=T, HW=HW, tile_hint=tile))
+
+
+def test_operand_swapped_projection_and_geglu_split_output(dev):
+    from geo4d_amd import ops, pack
+    F, N, C = 3, 200, 320
+    x = rnd((F * N, C), dev, 40)
+    wv = pack.pack_linear(rnd((C, C), dev, 41, 0.05), "bf16x3")
+    a, npa = ops.linear_t_batched(wv, x, F, N)
+    b, npb = ops.linear_t_batched(wv, make_split(x), F, N)
+    assert npa == npb and torch.equal(a, b)
+    # GEGLU epilogue writing the next GEMM's operand (every GEGLU-capable tile, first-generation hints are re-routed)
+    M, K, inner = 700, 256, 320
+    xg = rnd((M, K), dev, 42)
+    w, bb = rnd((2 * inner, K), dev, 43, 0.1), rnd((2 * inner,), dev, 44)
+    wp, bp = pack.pack_geglu(w, bb, "bf16x3")
+    for tile in (0, 1, 11, 13, 21, 22, 25, 27, 29, 31):
+        plain = ops.linear(xg, wp, bp, act=2, tile_hint=tile)
+        split = ops.linear(make_split(xg), wp, bp, act=2, tile_hint=tile, split_out=True)
+        hi, lo = decode_split(split)
+        h = xg @ w.t() + bb
+        ref = h[:, :inner] * TF.gelu(h[:, inner:])
+        assert ((hi + lo - ref).norm() / ref.norm()).item() < 3e-5, tile
+        assert ((hi + lo - plain).norm() / plain.norm()).item() < 2e-5, tile
+    w2 = pack.pack_linear(rnd((200, inner), dev, 45, 0.1), "bf16x3")
+    out = ops.linear(split, w2, None, residual=None)
+    assert ((out - ref @ rnd((200, inner), dev, 45, 0.1).t()).norm() / out.norm()).item() < 3e-5
+
+
+def test_presplit_network_equals_raw_network(dev):
+    """The tiny U-Net + VAE decode in bf16x3 with and without pre-split producers: same values up to the split's own rounding
+    (the GEMMs see identical hi / lo pairs either way, so the only differences are fp32 re-association from tile choices)."""
+    import os
+    from geo4d_amd import unet as U
+    from geo4d_amd.unet import UNetModel
+    from oracle.params import seeded_state_dict
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "unet_tiny.pt"), weights_only=False)
+    net = UNetModel(**dict(g["unet_config"], compute_dtype="bf16x3"))
+    net.load_state_dict(seeded_state_dict(g["shapes"]))
+    net = net.to(dev)
+    c = g["cases"]["t16_8x8"]
+    outs = {}
+    for flag in (True, False):
+        U.PRESPLIT = flag
+        try:
+            outs[flag] = net(torch.cat([c["x"], c["c_concat"]], 1).to(dev), c["t"].to(dev), context=c["context"].to(dev), fs=c["fs"].to(dev)).clone()
+        finally:
+            U.PRESPLIT = True
+    e = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
+    ref = ((outs[True].cpu() - c["out"]).norm() / c["out"].norm()).item()
+    print(f"[presplit vs raw tiny U-Net] rel_l2 = {e:.3e}; vs reference {ref:.3e}")
+    assert e < 1e-5 and ref < 2e-4

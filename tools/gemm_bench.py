@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--vendor", action="store_true", help="also time the vendor library on the same shape (hipBLASLt via F.linear, MIOpen via F.conv2d channels_last): a calibration point, never used by the product path")
     ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
     ap.add_argument("--explore2", action="store_true", help="per shape: best 32x32-MFMA configuration (tile hints 1..17) vs best second-generation one (21..29), and every 21..29 tile at split 1")
+    ap.add_argument("--tiles", default="", help="comma list of tile hints to time per shape (split 1), e.g. the ablation builds 40..64")
     ap.add_argument("--ablate", type=int, default=0, help="bf16x3 only: 1 = skip the in-register operand split (wrong numbers; measures its cost)")
     args = ap.parse_args()
     ops.DEBUG_ABLATE = args.ablate
@@ -136,6 +137,14 @@ def main():
             res.sort()
             print("    auto %.1f us | best: %s" % (us, "  ".join("t%d/s%d %.1f" % (t, s2, u) for u, t, s2 in res[:6])))
             us = min(us, res[0][0])
+        if args.tiles:
+            row = []
+            for t in args.tiles.split(","):
+                try:
+                    row.append("t%s %.1f" % (t, timeit(tile=int(t), split=1)))
+                except RuntimeError as e:
+                    row.append("t%s n/a" % t)
+            print("    " + "  ".join(row))
         if args.explore2:
             def sweep(tiles):
                 res = []
@@ -146,7 +155,7 @@ def main():
                         except RuntimeError:
                             pass
                 return sorted(res)
-            v1, v2 = sweep((1, 2, 3, 4, 11, 13, 16, 17)), sweep(range(21, 30))
+            v1, v2 = sweep((1, 2, 3, 4, 11, 13, 16, 17)), sweep(list(range(21, 30)) + [31, 33, 34, 35, 39])
             tot2 = globals().setdefault("_TOT2", [0.0, 0.0])
             tot2[0] += v1[0][0] * cnt / 1e3
             tot2[1] += v2[0][0] * cnt / 1e3
