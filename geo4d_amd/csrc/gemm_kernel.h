@@ -545,10 +545,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const geo4d_conv_gem
         if (p.R) v += load_res(p.R, bz * p.r_bs + (long)m * p.ldr + n + j, p.out_dtype);
         e[j] = v;
     }
-    if (p.o_split) {
-        store_split8((float*)p.O + bz * p.o_bs + (long)m * p.ldo, n >> 3, e);
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) store_out(p.O, bz * p.o_bs + (long)m * p.ldo + n + j, e[j], p.out_dtype);
 }

@@ -51,7 +51,8 @@ constexpr int v2_smem_bytes() { return (NA * BM + 2 * BN) * PITCH + BM * MAXTAP 
 // NA = number of A-panel (activation) buffers in the ring: 2 = both panels double-buffered; 3 = the gathered A panel runs TWO slabs
 // ahead (its rows come from HBM / the Infinity Cache, measured landing time of a lone 60 KB slab: 1.05-1.44 us against 1.2 us of
 // MFMA work per bf16x3 slab) while the L2-resident weight panel stays one slab ahead; 160 KB of LDS does not hold three full stages.
-template <typename T, int BM, int BN, int WM, int WN, int HOT, int NA = 2, int ABL = 0>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
+// OSPLIT: the GEGLU epilogue writes the pre-split operand format (o_split; a separate instantiation: the extra epilogue code costs registers)
+template <typename T, int BM, int BN, int WM, int WN, int HOT, int NA = 2, int ABL = 0, bool OSPLIT = false>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_conv_gemm_t p, const int splits, const int tiles_mn) {
     constexpr int NT = WM * WN * 64;
     constexpr int EPC = Elem<T>::EPC;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
                         }
                         const long oidx = obase + (long)m * ldo + oc;
                         if (vec_ok) {
-                            if (p.o_split) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
+                            if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
                             else if (odt == GEO4D_F32) *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
                             else if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
                             else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
@@ -329,8 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
 #pragma unroll
                             for (int j = 0; j < 4; ++j) e[j] += r[j];
                         }
-                        if (!partial && p.o_split) store_split4((float*)O + obase + (long)m * ldo, n >> 2, e);
-                        else *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
+                        *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
                     } else {
                         if (has_res) {
                             const u32x2 r = *(const u32x2*)((const unsigned short*)p.R + rbase + (long)m * p.ldr + n);
@@ -420,12 +420,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
 }
 
 // resident workgroups per launch = CUs x workgroups that fit a CU (queried once per kernel instantiation)
-template <typename T, int BM, int BN, int WM, int WN, int HOT, int NA = 2, int ABL = 0>
+template <typename T, int BM, int BN, int WM, int WN, int HOT, int NA = 2, int ABL = 0, bool OSPLIT = false>
 int launch_v2_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     constexpr int smem = v2_smem_bytes<BM, BN, NA>();
     static_assert(smem <= 160 * 1024, "LDS");
     static int resident = 0;
-    auto kern = conv_gemm_v2_kernel<T, BM, BN, WM, WN, HOT, NA, ABL>;
+    auto kern = conv_gemm_v2_kernel<T, BM, BN, WM, WN, HOT, NA, ABL, OSPLIT>;
     if (!resident) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
@@ -460,7 +460,15 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
         geo4d_set_error("conv_gemm v2: GEGLU needs wave tiles that are a multiple of 64 columns wide");
         return GEO4D_EINVAL;
     }
+    if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
     if constexpr (IsX3<T>::value) {
+        if (p.o_split) {
+            if constexpr ((BN / WN / 16) % 4 == 0) {
+                if (p.act == 2 && p.w_split && p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 2, NA, 0, true>(p, splits, stream);
+            }
+            geo4d_set_error("conv_gemm: o_split is built for the GEGLU epilogue (act 2) of pre-split x pre-split launches on GEGLU-capable tiles");
+            return GEO4D_EINVAL;
+        }
         if (p.w_split && !p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 1, NA>(p, splits, stream);
         if (p.w_split && p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 2, NA>(p, splits, stream);
     }

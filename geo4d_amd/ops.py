@@ -313,7 +313,7 @@ def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias
 _gn_ws = {}
 
 
-GN_ONE_LAUNCH = _os.environ.get("GEO4D_GN_ONE_LAUNCH", "1") != "0"   # statistics + merge + apply around a grid-wide barrier (norm.hip)
+GN_ONE_LAUNCH = _os.environ.get("GEO4D_GN_ONE_LAUNCH", "0") != "0"   # statistics + merge + apply around a grid-wide barrier (norm.hip)
 _gn_barrier = {}
 
 

@@ -72,10 +72,10 @@ typedef struct geo4d_conv_gemm_t {
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */
-    int o_split;         /* dtype 3 (bf16x3), out_dtype F32 only: O is written in the pre-split operand format ([8 x bf16 hi | 8 x bf16 lo]
-                            per 8 output columns; ldo / o_bs still count columns) - the producer side of a_split for GEMM chains
-                            (GEGLU -> FF out). Needs the vector epilogue (stored columns % 8 == 0, aligned rows), no residual,
-                            row-major output, no gn_colsum */
+    int o_split;         /* dtype 3 (bf16x3), a_split and w_split set, act 2 (GEGLU), out_dtype F32: O is written in the pre-split operand
+                            format ([8 x bf16 hi | 8 x bf16 lo] per 8 output columns; ldo / o_bs still count columns) - the producer
+                            side of a_split for the GEGLU -> FF-out chain. Stored columns % 8 == 0, aligned rows, no split-K;
+                            served by the GEGLU-capable second-generation tiles (first-generation hints are re-routed) */
     float* gn_colsum;    /* optional [M/32][N][2] fp32: per 32-row block and output column, (sum, sum of squares) of the values this
                             launch stores - the statistics pass of the GroupNorm that consumes O, produced for free by the epilogue
                             (geo4d_groupnorm_t.colsum). Needs M % 32 == 0, N % 8 == 0, row-major 16-byte aligned output, batch 1,
