@@ -15,9 +15,13 @@ per iteration for the same numbers.
 
 Initialisation follows ``init_im_poses.align_group`` / ``init_from_pts3d_group`` (:82-181, :569-635): windows are chained by
 confidence-weighted similarity registration (``roma.rigid_points_registration`` = weighted Umeyama, restated here), ``pw_poses``
-come from registering every window to the chained cloud, depths are the z of the cloud in each camera. DEVIATION: the reference
-finds every camera by OpenCV RANSAC-PnP (cv2.solvePnPRansac — absent here and not reproducible); this module takes the per-window
-camera-to-world matrices that the Plücker ray maps already give (geo4d_amd/rays.py, N2). The focals start, as in the reference,
+come from registering every window to the chained cloud, depths are the z of the cloud in each camera. The reference finds every
+camera by OpenCV RANSAC-PnP (cv2.solvePnPRansac, absent here): ``init_from_group(pose_init="pnp")`` follows it with the seeded
+restatement in geo4d_amd/pnp.py (same candidate focals, threshold and consensus rule; sampler and minimal solver differ and say so);
+the DEFAULT start takes the per-window camera-to-world matrices that the Plücker ray maps already give (geo4d_amd/rays.py, N2) —
+cheaper (no host loop over images) and equally close to the optimum on the fixtures. DEVIATION (second call): calling
+``compute_global_alignment`` again continues with the late terms ON from its first iteration, whereas the reference restarts its
+epoch counter (terms off until iteration 150, ``_set_st_depth`` re-run). The focals start, as in the reference,
 from the Weiszfeld estimate on every image's ray map (`estimate_focal_weiszfeld`, pinned on dust3r.post_process; the reference then
 lets PnP pick among that value and +-3 % of the image size).
 
@@ -114,6 +118,20 @@ def estimate_focal_weiszfeld(rays, pp=None, iters=10):
     return f
 
 
+def align_origin_and_rpe(est, ref):
+    """The two evo pieces of ``_set_traj`` (optimizer_group.py:242-268 -> dust3r/utils/vo_eval.py:174-266), restated (evo is not
+    installed): ``PosePath3D.align_origin`` = left-multiply the estimate by P = ref_0 est_0^-1, and the RPE rotation metric
+    (delta = 1 frame, all pairs, rotation_angle_deg): rmse of the angle of (Q_i^-1 Q_{i+1})^-1 (P_i^-1 P_{i+1}).
+    est, ref [S, 4, 4] float64 ndarrays -> (P [4, 4], rmse in degrees). Pinned on closed-form cases (tests/test_align_closed_form_cpu.py)."""
+    Pm = ref[0] @ np.linalg.inv(est[0])
+    al = Pm[None] @ est
+    ang = []
+    for k in range(len(est) - 1):
+        E = np.linalg.inv(np.linalg.inv(ref[k]) @ ref[k + 1]) @ (np.linalg.inv(al[k]) @ al[k + 1])
+        ang.append(np.degrees(np.arccos(np.clip((np.trace(E[:3, :3]) - 1) / 2, -1.0, 1.0))))
+    return Pm, float(np.sqrt(np.mean(np.square(ang))))
+
+
 def lr_at(t, schedule, lr_base, lr_min):
     """commons.py:102-110."""
     if schedule == "cosine":
@@ -124,8 +142,10 @@ def lr_at(t, schedule, lr_base, lr_min):
 
 
 class GroupAligner:
+    MAX_SLOTS = 6          # csrc/align.hip MAXS: windows per image the fused residual kernel unrolls
+
     def __init__(self, groups, pred, conf, shared_focal=True, temporal_smoothing_weight=0.0, translation_weight=0.1, base_scale=0.5,
-                 conf_clamp=10.0, chunk_pixels=4096, inverse_depth=None, traj=None, depth_traj_start_iter=150):
+                 conf_clamp=10.0, chunk_pixels=4096, inverse_depth=None, traj=None, depth_traj_start_iter=150, shard=None):
         """groups: list of G lists of S image indices; pred [G, S, H, W, 3], conf [G, S, H, W] fp32 on the HIP device;
         inverse_depth [G, S, H, W(, 1)] (the decoded inverse-depth modality mapped to [0, 1]) and traj [G, S, 4, 4] (every window's
         camera-to-world matrices in its own frame, N2) switch the two late terms on (pred_pts['inverse_depthmap'] / ['traj'],
@@ -142,10 +162,18 @@ class GroupAligner:
         self.shared_focal, self.tsw, self.tw, self.base_scale, self.conf_clamp = shared_focal, temporal_smoothing_weight, translation_weight, base_scale, conf_clamp
         self.norm_pw_scale = True
         e_all = [i for g in self.groups for i in g]
-        slots = [[s for s, i in enumerate(e_all) if i == img] for img in range(self.n)]
-        if any(len(s) == 0 for s in slots):
+        if any(not any(i == img for i in e_all) for img in range(self.n)):
             raise ValueError("every image must belong to at least one window")
+        self.shard = shard
+        local = set(range(G)) if shard is None else set(shard.local_groups)
+        self.local_groups = sorted(local)
+        self.primary = shard is None or shard.primary          # evaluates the pose-only terms (temporal smoothing, trajectory)
+        slots = [[s for s, i in enumerate(e_all) if i == img and (s // S) in local] for img in range(self.n)]
         self.max_slots = max(len(s) for s in slots)
+        if self.max_slots > self.MAX_SLOTS:
+            raise NotImplementedError(f"an image belongs to {self.max_slots} windows; the fused residual kernel handles {self.MAX_SLOTS} "
+                                      "(window stride >= 3 at 16 frames per window)")
+        self.n_local_slots = sum(len(s) for s in slots)
         ptr = np.concatenate([[0], np.cumsum([len(s) for s in slots])]).astype(np.int32)
         self.slot_ptr = torch.from_numpy(ptr).to(self.dev)
         self.slot_idx = torch.tensor([s for lst in slots for s in lst], dtype=torch.int32, device=self.dev)
@@ -249,7 +277,8 @@ class GroupAligner:
         _lib.check(self.lib.geo4d_align_residual(C.byref(a), ops._stream()), "geo4d_align_residual")
         I = self._img_sums
         # slot sums come back in CSR (image-major) order: put them in slot order, then add the S frames of each window
-        Ssum = torch.zeros_like(self._slot_sums).index_copy_(0, self.slot_order, self._slot_sums).reshape(self.G, self.S, -1).sum(1)
+        # (with a shard only this rank's slots are listed: rows past n_local_slots are not written)
+        Ssum = torch.zeros_like(self._slot_sums).index_copy_(0, self.slot_order, self._slot_sums[:self.n_local_slots]).reshape(self.G, self.S, -1).sum(1)
         loss = I[:, 13].sum()
         # chain rule through the tiny parameter -> matrix maps: d loss = <dL/dR, dR> + <dL/dt, dt> + dL/df df + <dL/dsR, dsR> + <dL/dst, dst>
         surrogate = (I[:, :9].reshape(self.n, 3, 3) * R).sum() + (I[:, 9:12] * t).sum() + (I[:, 12:13] * f).sum() + \
@@ -257,7 +286,7 @@ class GroupAligner:
         if depth_on:
             surrogate = surrogate + (Ssum[:, 12:13] * small["s_depth"]).sum() + (Ssum[:, 13:14] * small["t_depth"]).sum()
         eye = torch.eye(3, device=self.dev)
-        if "traj_align_poses" in late:
+        if "traj_align_poses" in late and self.primary:
             # optimizer_group.py:496-512: T_g [R_k | e^l t_k] against the cameras of the window's images (rigid inverse written out)
             vg, idx = self._traj_vg, self._traj_idx          # device index tensors made once at the start-up (capturable)
             tap = small["traj_align_poses"].index_select(0, vg)
@@ -271,7 +300,7 @@ class GroupAligner:
             ltraj = 0.005 * (torch.norm(rel_R - eye, dim=(1, 2)) + torch.norm(rel_t, dim=1) * self.tw).sum()
             surrogate = surrogate + ltraj
             loss = loss + ltraj.detach()
-        if self.tsw > 0 and self.n > 1:
+        if self.tsw > 0 and self.n > 1 and self.primary:
             # relative_pose_loss (optimizer_group.py:529-541): inverse(RT1) @ RT2 with RT rigid, so inverse = [R^T | -R^T t]
             # (no batched LU on the device: keeps the iteration capturable)
             Rt = R[:-1].transpose(1, 2)
@@ -280,8 +309,10 @@ class GroupAligner:
             surrogate = surrogate + self.tsw * smooth
             loss = loss + self.tsw * smooth.detach()
         surrogate.backward()
-        grads = {k: v.grad for k, v in small.items()}
+        grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in small.items()}
         grads["im_depthmaps"] = self._grad_ld
+        if self.shard is not None:
+            loss, grads = self.shard.reduce(loss, grads)        # one all-reduce: loss, small gradients, depth gradients of shared images
         return loss, grads
 
     # ---- start-up of the two late terms -------------------------------------------------------------------------------------------
@@ -307,14 +338,19 @@ class GroupAligner:
         _lib.check(self.lib.geo4d_lad_target(self.P["im_depthmaps"].data_ptr(), self.slot_img.data_ptr(), target.data_ptr(), G * S, HW, ops._stream()),
                    "geo4d_lad_target")
         ws = torch.empty(self.lib.geo4d_lad_workspace(G, S * HW), dtype=torch.uint8, device=self.dev)
-        st, best = self._lad_fit(target, None, 1e-2, 5000, ws)
-        retry = [1 if b < 0.8 else 0 for b in best]
+        mine = None if self.shard is None else [1 if g in set(self.local_groups) else 0 for g in range(G)]    # a rank fits its own windows
+        st, best = self._lad_fit(target, mine, 1e-2, 5000, ws)
+        retry = [1 if (b < 0.8 and (mine is None or mine[g])) else 0 for g, b in enumerate(best)]
         if any(retry):
             for lr in (1e-4, 1e-3):
                 st2, d2 = self._lad_fit(target, retry, lr, 3000, ws)
                 for g in range(G):
                     if retry[g] and d2[g] > best[g]:
                         st[g], best[g] = st2[g], d2[g]
+        if self.shard is not None:
+            tab = torch.cat([st, torch.tensor(best, device=self.dev, dtype=st.dtype).reshape(G, 1).nan_to_num()], 1)
+            tab = self.shard.merge_rows(tab.nan_to_num(), self.local_groups)
+            st, best = tab[:, :2].contiguous(), tab[:, 2].tolist()
         self.P["s_depth"].copy_(st[:, :1])
         self.P["t_depth"].copy_(st[:, 1:])
         self.depth_delta = best
@@ -333,16 +369,11 @@ class GroupAligner:
             est = traj[g].copy()
             est[:, :3, 3] *= scale[g]
             ref = im[grp]
-            Pm = ref[0] @ np.linalg.inv(est[0])
-            al = Pm[None] @ est
-            ang = []
-            for k in range(self.S - 1):
-                E = np.linalg.inv(np.linalg.inv(ref[k]) @ ref[k + 1]) @ (np.linalg.inv(al[k]) @ al[k + 1])
-                ang.append(np.degrees(np.arccos(np.clip((np.trace(E[:3, :3]) - 1) / 2, -1.0, 1.0))))
+            Pm, rpe = align_origin_and_rpe(est, ref)
             self.P["traj_align_poses"][g, :4] = rotmat_to_quat(torch.from_numpy(Pm[:3, :3])).to(self.dev)
             self.P["traj_align_poses"][g, 4:7] = signed_log1p(torch.from_numpy(Pm[:3, 3])).float().to(self.dev)
             self.P["traj_align_poses"][g, 7] = float(np.log(scale[g]))
-            if float(np.sqrt(np.mean(np.square(ang)))) < 4:
+            if rpe < 4:
                 valid.append(g)
         return valid
 
@@ -372,6 +403,8 @@ class GroupAligner:
         phases around the start-up at iteration `depth_traj_start_iter` (which synchronises with the host once)."""
         b1 = b2 = 0.9
         eps = 1e-8
+        if self.shard is not None and self.shard.active:
+            use_graph = False                                  # the per-iteration all-reduce runs on RCCL's stream: eager launches
         steps = torch.arange(1, niter + 1, dtype=torch.float64)
         lrs = torch.tensor([lr_at(it / niter, schedule, lr, lr_min) for it in range(niter)], dtype=torch.float64)
         table = torch.stack([lrs, 1 - b1 ** steps, (1 - b2 ** steps).sqrt()], 1).float().to(self.dev)            # [niter, 3]
@@ -438,13 +471,21 @@ class GroupAligner:
                 run_phase(start, niter)
         else:                                               # terms already started (a second call continues with them on)
             run_phase(0, niter)
+        if self.shard is not None:                             # every image's depth map from the rank that owns it
+            self.P["im_depthmaps"].copy_(self.shard.gather_depthmaps(self.P["im_depthmaps"]))
         hist = losses.tolist() if history else None
         return float(losses[-1]) if niter else float("inf"), hist
 
     # ---- initialisation (init_im_poses.py:82-181, 569-635) ----------------------------------------------------------------------
     @torch.no_grad()
-    def init_from_group(self, traj, focal=None, raymaps=None):
-        """traj [G, S, 4, 4]: camera-to-world of every frame in its window's own frame (the Plücker cameras of N2);
+    def init_from_group(self, traj, focal=None, raymaps=None, pose_init="traj", niter_PnP=100, pnp_seed=0):
+        """pose_init = "pnp": the reference's initialisation (init_im_poses.align_group :82-214): windows chained by registration
+        WITHOUT overwriting an image's first estimate, every camera from seeded RANSAC-PnP of its chained point map against the
+        pixel grid (geo4d_amd/pnp.py, confidence > 0.5), tried at the image's ray-map focal and -/+ 3 % of the image size; images of
+        the FIRST window take the winning candidate as their focal, the others keep the ray-map estimate (as the reference's
+        `if im_focals[img_idx] is None` leaves them); the shared focal is the mean. `traj` is then only used by the trajectory term.
+        pose_init = "traj" (default): cameras from the Plücker ray maps instead (below).
+        traj [G, S, 4, 4]: camera-to-world of every frame in its window's own frame (the Plücker cameras of N2);
         focal: pixels; raymaps [G, S, H, W, 3] (pred_pts['raydir']): when given and `focal` is None, every image's focal is the
         Weiszfeld estimate on its first ray map and the shared focal their mean, as align_group / init_from_pts3d_group do
         (init_im_poses.py:133-136, 183-185, 627-628); with neither, the focal is estimated from window 0's first point map."""
@@ -453,6 +494,8 @@ class GroupAligner:
         conf = self.conf.reshape(G, S, H * W)
         pts3d, conf_list, im_poses = [None] * self.n, [None] * self.n, [None] * self.n
         done = set()
+        if pose_init == "pnp":
+            return self._init_pnp(pred, conf, focal, raymaps, niter_PnP, pnp_seed)
         for k, i in enumerate(self.groups[0]):
             pts3d[i], conf_list[i], im_poses[i] = pred[0, k].clone(), conf[0, k].clone(), traj[0, k].clone().float()
             done.add(i)
@@ -513,13 +556,91 @@ class GroupAligner:
         return self
 
 
+def _init_pnp(self, pred, conf, focal, raymaps, niter_PnP, seed):
+    """GroupAligner.init_from_group(pose_init="pnp"): align_group + init_from_pts3d_group of the reference (see the docstring there)."""
+    from . import pnp
+    G, S, H, W = self.G, self.S, self.H, self.W
+    pts3d, conf_list, im_poses, im_focals = [None] * self.n, [None] * self.n, [None] * self.n, [None] * self.n
+    rm = None if raymaps is None else raymaps.reshape(G, S, H, W, 3)
+
+    def ray_focal(g, k):
+        return None if rm is None else float(estimate_focal_weiszfeld(rm[g, k][None].to(self.dev))[0])
+
+    def run_pnp(i, g, k):
+        msk = (conf[g, k] > 0.5).reshape(H, W).cpu().numpy()
+        return pnp.fast_pnp(pts3d[i].reshape(H, W, 3).double().cpu().numpy(), im_focals[i], msk, niter_PnP=niter_PnP, seed=seed + i)
+    done = set()
+    for k, i in enumerate(self.groups[0]):                                  # the first window is the world frame
+        pts3d[i], conf_list[i] = pred[0, k].clone(), conf[0, k].clone()
+        im_focals[i] = ray_focal(0, k)
+        res = run_pnp(i, 0, k)
+        if res:
+            im_focals[i], im_poses[i] = res[0], torch.from_numpy(res[1]).float().to(self.dev)
+        if im_poses[i] is None:
+            im_poses[i] = torch.eye(4, device=self.dev)
+        done.add(i)
+    for g in range(1, G):
+        grp = self.groups[g]
+        assert grp[0] in done, "the first image of every window must belong to an earlier window"
+        seen = [k for k, i in enumerate(grp) if i in done]
+        s, R, T = rigid_points_registration(pred[g, seen], torch.stack([pts3d[grp[k]] for k in seen]),
+                                            torch.stack([conf[g, k] * conf_list[grp[k]] for k in seen]))
+        for k, i in enumerate(grp):
+            if pts3d[i] is None:                                            # an image keeps its FIRST chained estimate
+                pts3d[i], conf_list[i] = s * (pred[g, k] @ R.t()) + T, conf[g, k].clone()
+                done.add(i)
+            if im_focals[i] is None:
+                im_focals[i] = ray_focal(g, k)
+            res = run_pnp(i, g, k)
+            if res:
+                if im_poses[i] is None:
+                    im_poses[i] = torch.from_numpy(res[1]).float().to(self.dev)
+                if im_focals[i] is None:
+                    im_focals[i] = res[0]
+            if im_poses[i] is None:
+                im_poses[i] = torch.eye(4, device=self.dev)
+    for g, grp in enumerate(self.groups):                                   # pairwise poses: every window onto the chained cloud
+        s, R, T = rigid_points_registration(pred[g], torch.stack([pts3d[i] for i in grp]), torch.stack([conf[g, k] * conf_list[i] for k, i in enumerate(grp)]))
+        self.P["pw_poses"][g, :4] = rotmat_to_quat(R).to(self.dev)
+        self.P["pw_poses"][g, 4:7] = signed_log1p(T / s)
+        self.P["pw_poses"][g, 7] = torch.log(s)
+    sf = float((math.log(self.base_scale) - self.P["pw_poses"][:, -1].mean()).exp()) if self.norm_pw_scale else 1.0
+    self.init_focals = torch.tensor([f if f is not None else float(max(H, W)) for f in im_focals], device=self.dev)
+    if focal is not None:
+        self.P["im_focals"][:] = FOCAL_BREAK * (torch.log(focal) if torch.is_tensor(focal) else math.log(focal))
+    elif self.shared_focal:
+        self.P["im_focals"][:] = FOCAL_BREAK * math.log(float(self.init_focals.mean()))
+    else:
+        self.P["im_focals"][:, 0] = FOCAL_BREAK * torch.log(self.init_focals)
+    sky = 0.0
+    for i in range(self.n):
+        M = im_poses[i].clone()
+        M[:3, 3] *= sf
+        Rw, tw = M[:3, :3], M[:3, 3]
+        depth = ((pts3d[i] * sf - tw) @ Rw)[:, 2]
+        skym = conf_list[i] < 1e-4
+        if i == 0:
+            sky = depth.max()
+        depth = torch.where(skym, torch.as_tensor(sky, device=self.dev), depth)
+        self.P["im_depthmaps"][i] = depth.clamp_min(1e-6).log().nan_to_num(neginf=0)
+        self.P["im_poses"][i, :4] = rotmat_to_quat(Rw).to(self.dev)
+        self.P["im_poses"][i, 4:7] = signed_log1p(tw)
+    return self
+
+
+GroupAligner._init_pnp = _init_pnp
+
+
 def post_optimization(slices, maps, traj, args=None, conf_optimize=True, lr=0.03, align=True, intrinsics=None,
-                      use_raymap=True, use_inverse_depthmap=True, use_traj=True, pointmap_vae_used=True, depth_traj_start_iter=150):
+                      use_raymap=True, use_inverse_depthmap=True, use_traj=True, pointmap_vae_used=True, depth_traj_start_iter=150,
+                      sharded=None, pose_init="traj"):
     """The consumer of the gathered clip: ``post_optimization`` of scripts/evaluation/test_geo4d.py:30-51 with the pred_list its
     window loop builds (:446-501). ``slices`` / ``maps [n_windows, 11, T, H, W]`` / ``traj [n_windows, T, 4, 4]`` are what
     ``pipeline.run_clip(..., with_cameras=True)`` returns; ``args`` = the config's ``postprocess`` tree (a dict or any object with
     n_iter / pose_schedule / temporal_smoothing_weight / translation_weight / not_shared_focal / use_gt_focal attributes; None =
-    the shipped values). Returns the optimised ``GroupAligner`` (``get_depthmaps`` / ``get_im_poses_matrix`` / ``get_focals``).
+    the shipped values). ``sharded``: None = shard the optimisation over the ranks of the default process group when there is one
+    (align_dist.AlignShard: every rank evaluates its block of windows, one all-reduce per iteration), False = replicate it.
+    Returns the optimised ``GroupAligner`` (``get_depthmaps`` / ``get_im_poses_matrix`` / ``get_focals``).
     ``intrinsics [n_images, 3, 3]`` presets the focals and freezes them (scene.preset_focal(..., requires_grad=False) in the script)."""
     from .pipeline import postprocess_window
     get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
@@ -530,7 +651,12 @@ def post_optimization(slices, maps, traj, args=None, conf_optimize=True, lr=0.03
     conf = torch.stack([p["conf"][..., 0] for p in post])
     if not conf_optimize:
         conf = torch.ones_like(conf)
-    scene = GroupAligner(groups, torch.stack([p["pts3d"] for p in post]), conf,
+    shard = None
+    if sharded or (sharded is None and torch.distributed.is_available() and torch.distributed.is_initialized()
+                   and torch.distributed.get_world_size() > 1):
+        from .align_dist import AlignShard
+        shard = AlignShard(groups, 1 + max(max(g) for g in groups))
+    scene = GroupAligner(groups, torch.stack([p["pts3d"] for p in post]), conf, shard=shard,
                          shared_focal=not get("not_shared_focal", False) and not get("use_gt_focal", False),
                          temporal_smoothing_weight=get("temporal_smoothing_weight", 0.015), translation_weight=get("translation_weight", 1.0),
                          inverse_depth=torch.stack([p["inverse_depthmap"] for p in post]) if use_inverse_depthmap else None,
@@ -539,7 +665,7 @@ def post_optimization(slices, maps, traj, args=None, conf_optimize=True, lr=0.03
     if intrinsics is not None:
         per_image = (intrinsics[:, 0, 0] + intrinsics[:, 1, 1]) / 2.0
         focal = per_image.to(scene.dev).float() if not scene.shared_focal else float(per_image.float().mean())
-    scene.init_from_group(traj, focal=focal, raymaps=torch.stack([p["raymap"] for p in post]) if use_raymap else None)
+    scene.init_from_group(traj, focal=focal, raymaps=torch.stack([p["raymap"] for p in post]) if use_raymap else None, pose_init=pose_init)
     if intrinsics is not None:
         scene.frozen.add("im_focals")
     if align:

@@ -1,0 +1,101 @@
+"""Global alignment sharded over the GPUs of one node (BASELINE.json north_star: "... dust3r/cloud_opt point-map alignment shard over the
+8 GPUs"; SURVEY.md §8(e) last row).
+
+What shards: the residual terms of ``LightPointCloudGroupOptimizer.forward`` (optimizer_group.py:440-525) are a SUM over windows
+(groups) — the confidence-weighted point-map residual and the inverse-depth residual touch one window's prediction each — while the
+parameters are per image (log-depth map, pose), per window (sim(3) ``pw_poses``, s / t of the depth fit, trajectory alignment) or
+global (shared focal). So windows are dealt to ranks in CONTIGUOUS blocks (consecutive windows share 12 of their 16 images: a block
+keeps those images on one rank), every rank evaluates the fused residual kernel over its own windows only, and ONE all-reduce per
+iteration sums
+    [ loss | d/d im_poses (n x 7) | d/d im_focals | d/d pw_poses (G x 8) | late-term parameters | d/d log-depth of the SHARED images ]
+where "shared" = images whose windows live on more than one rank (the block boundaries: 12 images each). Depth maps of images that
+belong to one rank only never leave it until the end: their gradients are complete locally, and `gather_depthmaps` assembles the final
+maps from each image's owner. Every rank then applies the identical Adam update to the replicated small parameters, so the ranks
+stay bit-identical without a broadcast. Pose-only terms (temporal smoothing, trajectory) are a few dozen flops: rank 0 evaluates them.
+
+The start-up of the inverse-depth term (``_set_st_depth``, one least-absolute-deviation fit per window) shards the same way: a rank
+fits its own windows, `merge_rows` all-reduces the [G, 3] table of (s, t, delta score).
+
+Backend: torch.distributed — "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests (tests/test_dist_cpu.py drives this class
+with the oracle's objective: world 2 == world 1 to fp32 round-off).
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition_windows(num_windows, rank, world):
+    """Contiguous block of windows of `rank` (sizes differ by at most one). Every rank computes the same table."""
+    base, extra = divmod(num_windows, world)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+class AlignShard:
+    def __init__(self, groups, n_images, rank=None, world=None, group=None):
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        self.groups = [list(g) for g in groups]
+        self.G, self.n = len(self.groups), n_images
+        self.blocks = [partition_windows(self.G, r, self.world) for r in range(self.world)]
+        self.local_groups = self.blocks[self.rank]
+        touch = [set() for _ in range(n_images)]
+        for r, blk in enumerate(self.blocks):
+            for g in blk:
+                for i in self.groups[g]:
+                    touch[i].add(r)
+        self.owner = [min(t) if t else 0 for t in touch]               # the rank whose copy of an image's depth map is final
+        self.shared = [i for i, t in enumerate(touch) if len(t) > 1]   # images whose depth gradient needs the all-reduce
+        self.primary = self.rank == 0                                   # evaluates the pose-only terms
+        self._shared_idx = None
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def _all_reduce(self, t):
+        if self.active:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def reduce(self, loss, grads):
+        """Sum the local objective over ranks IN PLACE: loss (0-dim), every small gradient, and the depth-map gradient rows of the
+        shared images — one flat all-reduce."""
+        if not self.active:
+            return loss, grads
+        depth = grads["im_depthmaps"]
+        if self._shared_idx is None or self._shared_idx.device != depth.device:
+            self._shared_idx = torch.tensor(self.shared, dtype=torch.long, device=depth.device)
+        keys = sorted(k for k in grads if k != "im_depthmaps")
+        parts = [loss.reshape(1).float()] + [grads[k].reshape(-1).float() for k in keys]
+        if len(self.shared):
+            parts.append(depth.index_select(0, self._shared_idx).reshape(-1))
+        flat = self._all_reduce(torch.cat(parts))
+        off = 1
+        loss = flat[0]
+        for k in keys:
+            n = grads[k].numel()
+            grads[k] = flat[off:off + n].reshape(grads[k].shape).to(grads[k].dtype)
+            off += n
+        if len(self.shared):
+            depth.index_copy_(0, self._shared_idx, flat[off:].reshape(len(self.shared), -1))
+        return loss, grads
+
+    def merge_rows(self, table, local_rows):
+        """[G, k] table whose rows `local_rows` were computed here: zero the others, all-reduce -> complete table on every rank."""
+        if not self.active:
+            return table
+        keep = torch.zeros(table.shape[0], 1, dtype=table.dtype, device=table.device)
+        keep[list(local_rows)] = 1
+        return self._all_reduce(table * keep)
+
+    def gather_depthmaps(self, depth):
+        """[n, HW] log-depth maps: every image from its owner rank (ranks that do not hold an image keep its initial value)."""
+        if not self.active:
+            return depth
+        own = torch.tensor([1.0 if o == self.rank else 0.0 for o in self.owner], dtype=depth.dtype, device=depth.device).unsqueeze(1)
+        return self._all_reduce(depth * own)
+
+    def bytes_per_iteration(self, HW, n_small):
+        """Payload of the per-iteration all-reduce in bytes."""
+        return 4 * (1 + n_small + len(self.shared) * HW)

@@ -172,3 +172,93 @@ def save_rgb_imgs(path, imgs):
     from PIL import Image
     for i, img in enumerate(imgs):
         Image.fromarray((np.asarray(img) * 255).astype(np.uint8)).save(f'{path}/frame_{i:04d}.png')
+
+
+# ---- glb export (dust3r/demo.py:56-86 -> dust3r/utils/viz_demo.py:13-58) -------------------------------------------------------------
+OPENGL = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]], dtype=np.float64)     # dust3r/viz.py:338-341
+
+
+def _glb_bytes(meshes, transform):
+    """Binary glTF 2.0 with one node per primitive. meshes: list of dict(mode, positions f32 [n, 3], colors u8 [n, 4] or None).
+    `transform` (4x4) is applied to every node, as trimesh.Scene.apply_transform does."""
+    import json
+    import struct
+    buf = bytearray()
+    views, accessors, gl_meshes, nodes = [], [], [], []
+
+    def add(data, target, ctype, atype, normalized=False, minmax=False):
+        while len(buf) % 4:
+            buf.append(0)
+        views.append({"buffer": 0, "byteOffset": len(buf), "byteLength": data.nbytes, "target": target})
+        buf.extend(data.tobytes())
+        acc = {"bufferView": len(views) - 1, "componentType": ctype, "count": int(data.shape[0]), "type": atype}
+        if normalized:
+            acc["normalized"] = True
+        if minmax:
+            acc["min"], acc["max"] = [float(v) for v in data.min(0)], [float(v) for v in data.max(0)]
+        accessors.append(acc)
+        return len(accessors) - 1
+    for m in meshes:
+        pos = np.ascontiguousarray(m["positions"], dtype=np.float32)
+        attrs = {"POSITION": add(pos, 34962, 5126, "VEC3", minmax=True)}
+        if m.get("colors") is not None:
+            attrs["COLOR_0"] = add(np.ascontiguousarray(m["colors"], dtype=np.uint8), 34962, 5121, "VEC4", normalized=True)
+        gl_meshes.append({"primitives": [{"attributes": attrs, "mode": m["mode"]}]})
+        nodes.append({"mesh": len(gl_meshes) - 1, "matrix": [float(v) for v in np.asarray(transform, np.float64).T.reshape(-1)]})   # column-major
+    doc = {"asset": {"version": "2.0", "generator": "geo4d_amd.io"}, "scene": 0, "scenes": [{"nodes": list(range(len(nodes)))}],
+           "nodes": nodes, "meshes": gl_meshes, "accessors": accessors, "bufferViews": views, "buffers": [{"byteLength": len(buf)}]}
+    js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
+    js += b" " * (-len(js) % 4)
+    while len(buf) % 4:
+        buf.append(0)
+    total = 12 + 8 + len(js) + 8 + len(buf)
+    return b"glTF" + struct.pack("<II", 2, total) + struct.pack("<I", len(js)) + b"JSON" + js + struct.pack("<I", len(buf)) + b"BIN\x00" + bytes(buf)
+
+
+def _camera_wireframe(c2w, focal, imsize, screen_width):
+    """Line list of a camera pyramid: apex at the camera centre, base = the image plane at depth `screen_width * focal / W` scaled so
+    that the base is `screen_width` wide (dust3r/viz.py add_scene_cam draws a 4-sided cone of that size; here its 8 edges)."""
+    W, H = imsize
+    d = screen_width * focal / W
+    hw, hh = screen_width / 2.0, screen_width * H / W / 2.0
+    corners = np.array([[-hw, -hh, d], [hw, -hh, d], [hw, hh, d], [-hw, hh, d]], np.float64)
+    world = corners @ c2w[:3, :3].T + c2w[:3, 3]
+    apex = c2w[:3, 3]
+    segs = []
+    for k in range(4):
+        segs += [apex, world[k], world[k], world[(k + 1) % 4]]
+    return np.asarray(segs, np.float32)
+
+
+def save_glb(path, imgs, pts3d, masks, focals, cams2world, cam_size=0.05, show_cam=True, cam_color=None):
+    """convert_scene_output_to_glb(as_pointcloud=True) without trimesh: the masked points of every image with their colours as ONE
+    POINTS primitive, one LINES primitive per camera (pyramid edges, viridis-like colour ramp unless `cam_color` [n][3] in 0-255), and
+    the reference's scene transform inv(cams2world[0] @ OPENGL @ rot_y(180 deg)) on every node.
+    imgs [n, H, W, 3] in [0, 1]; pts3d [n, H, W, 3]; masks [n, H, W] bool; focals [n]; cams2world [n, 4, 4]. Returns `path`."""
+    to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    imgs, pts3d, masks, focals, cams2world = (to_np(v) for v in (imgs, pts3d, masks, focals, cams2world))
+    assert len(pts3d) == len(masks) <= len(imgs) <= len(cams2world) == len(np.reshape(focals, -1))
+    masks = masks.astype(bool)
+    pts = np.concatenate([p[m] for p, m in zip(pts3d, masks)]).reshape(-1, 3)
+    col = np.concatenate([im[m] for im, m in zip(imgs, masks)]).reshape(-1, 3)
+    col = np.concatenate([np.clip(col * 255.0 + 0.5, 0, 255).astype(np.uint8), np.full((len(col), 1), 255, np.uint8)], 1)
+    meshes = [dict(mode=0, positions=pts, colors=col)]
+    n = len(cams2world)
+    if show_cam:
+        H, W = imgs.shape[1:3]
+        for i in range(n):
+            if cam_color is not None:
+                c = np.asarray(cam_color[i] if isinstance(cam_color, list) else cam_color, np.float64)
+            else:
+                t = i / max(n - 1, 1)                                       # dark violet -> green -> yellow (viridis end points)
+                c = 255 * np.array([0.267 + 0.726 * t ** 2, 0.005 + 0.90 * t, 0.329 + 0.3 * np.sin(np.pi * t) - 0.19 * t])
+            seg = _camera_wireframe(cams2world[i].astype(np.float64), float(np.reshape(focals, -1)[i]), (W, H), cam_size)
+            cc = np.tile(np.concatenate([np.clip(c, 0, 255), [255.0]]).astype(np.uint8), (len(seg), 1))
+            meshes.append(dict(mode=1, positions=seg, colors=cc))
+    rot = np.eye(4)
+    rot[:3, :3] = np.array([[-1.0, 0, 0], [0, 1, 0], [0, 0, -1.0]])                     # Rotation.from_euler('y', 180 deg)
+    transform = np.linalg.inv(cams2world[0].astype(np.float64) @ OPENGL @ rot)
+    data = _glb_bytes(meshes, transform)
+    with open(path, "wb") as f:
+        f.write(data)
+    return path

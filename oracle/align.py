@@ -113,12 +113,15 @@ def rigid_inverse(M):
 
 
 def alignment_loss(P, data, temporal_smoothing_weight=0.0, translation_weight=0.1, focal_break=20.0, base_scale=0.5,
-                   norm_pw_scale=True, conf_clamp=10.0, state=None):
+                   norm_pw_scale=True, conf_clamp=10.0, state=None, local_groups=None, pose_terms=True):
     """P: dict(im_depthmaps [n, HW] (log depth), im_poses [n, 7], im_focals [1 or n, 1] (focal_break * log f), pw_poses [G, 8]
     [, s_depth [G, 1], t_depth [G, 1], traj_align_poses [G, 8]]);
     data: dict(pred [G*S, HW, 3], conf [G*S, HW], e_all int64 [G*S] image of every (group, slot), H, W
     [, invdepth [G*S, HW] predicted inverse depth, traj [G*S, 4, 4] per-window camera-to-world]);
-    state: None before `depth_traj_start_iter`; afterwards dict(invalid_depth_groups, valid_traj_groups) from start_depth_traj."""
+    state: None before `depth_traj_start_iter`; afterwards dict(invalid_depth_groups, valid_traj_groups) from start_depth_traj.
+    local_groups / pose_terms (checker of geo4d_amd/align_dist.py): the part of the objective ONE rank of a sharded run evaluates -
+    the window terms of `local_groups` only (normalised by the GLOBAL area, scales normalised over ALL windows) and the pose-only
+    terms (temporal smoothing, trajectory) only where `pose_terms`; the sum over a partition of the windows is the full loss."""
     n, HW = P["im_depthmaps"].shape
     H, W = data["H"], data["W"]
     G = P["pw_poses"].shape[0]
@@ -142,7 +145,12 @@ def alignment_loss(P, data, temporal_smoothing_weight=0.0, translation_weight=0.
     aligned = data["pred"] @ pw[:, :3, :3].transpose(1, 2) + pw[:, None, :3, 3]
     wgt = data["conf"].clamp(max=conf_clamp)
     total_area = float(data["pred"].shape[0] * HW)
-    li = ((pts[data["e_all"]] - aligned).norm(dim=-1) * wgt).sum() / total_area
+    gmask = torch.ones(G, device=dev)
+    if local_groups is not None:
+        gmask = torch.zeros(G, device=dev)
+        gmask[list(local_groups)] = 1
+    smask = gmask.repeat_interleave(S).reshape(G * S, 1)
+    li = ((pts[data["e_all"]] - aligned).norm(dim=-1) * wgt * smask).sum() / total_area
     loss = li
     if state is not None and data.get("invdepth") is not None:
         # optimizer_group.py:470-494: | 1 / (depth + 1e-6) - (s_g q + t_g) | where q > 0.05 and the window's fit was accepted, x 2
@@ -152,8 +160,8 @@ def alignment_loss(P, data, temporal_smoothing_weight=0.0, translation_weight=0.
         w = (data["invdepth"] > 0.05).float().reshape(G, S, HW).clone()
         if len(state["invalid_depth_groups"]):
             w[state["invalid_depth_groups"]] = 0
-        loss = loss + 2 * ((inv[data["e_all"]] - (data["invdepth"] * s + t)).abs() * w.reshape(G * S, HW)).sum() / total_area
-    if state is not None and data.get("traj") is not None and len(state["valid_traj_groups"]):
+        loss = loss + 2 * ((inv[data["e_all"]] - (data["invdepth"] * s + t)).abs() * w.reshape(G * S, HW) * smask).sum() / total_area
+    if pose_terms and state is not None and data.get("traj") is not None and len(state["valid_traj_groups"]):
         # optimizer_group.py:496-512
         vg = state["valid_traj_groups"]
         sc = P["traj_align_poses"][:, -1].exp()[vg]
@@ -163,7 +171,7 @@ def alignment_loss(P, data, temporal_smoothing_weight=0.0, translation_weight=0.
         moved = (RT[:, None] @ moved).reshape(-1, 4, 4)
         idx = data["e_all"].reshape(G, S)[vg].reshape(-1)
         loss = loss + 0.005 * relative_pose_loss(moved, im_poses[idx], translation_weight).sum()
-    if temporal_smoothing_weight > 0:
+    if pose_terms and temporal_smoothing_weight > 0:
         loss = loss + temporal_smoothing_weight * relative_pose_loss(im_poses[:-1], im_poses[1:], translation_weight).sum()
     return loss
 

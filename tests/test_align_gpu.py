@@ -56,12 +56,8 @@ def test_alignment_loop_vs_reference(fix, dev, graph):
     assert max(errs.values()) < 2e-3, errs
 
 
-def test_init_from_group_and_convergence_at_window_size(dev):
-    """A 28-frame / 4-window scene at 40x64 pixels per frame (the latent-resolution stand-in for 16-frame windows with stride 4):
-    registration-chained initialisation from the windows' own cameras, then 60 iterations; checked against the autograd oracle
-    evaluated at the same parameters, and for actually aligning the clip."""
-    from geo4d_amd.align import GroupAligner
-    from oracle import align as oalign
+def _scene28():
+    """28 frames / 4 windows of 16 (stride 4) at 40x64: ground-truth cameras, per-window predictions in the window's own frame and scale."""
     gen = torch.Generator().manual_seed(4)
     n, S, stride, H, W, f = 28, 16, 4, 40, 64, 55.0
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
@@ -84,6 +80,18 @@ def test_init_from_group_and_convergence_at_window_size(dev):
         tr = torch.stack([w2c @ c2w[i] for i in grp])
         tr[:, :3, 3] *= sc
         trajs.append(tr)
+    rays = torch.cat([(grid - pp) / f, torch.ones(H, W, 1)], -1)
+    return dict(groups=groups, preds=preds, confs=confs, trajs=trajs, c2w=c2w, f=f, n=n, S=S, H=H, W=W, rays=rays)
+
+
+def test_init_from_group_and_convergence_at_window_size(dev):
+    """A 28-frame / 4-window scene at 40x64 pixels per frame (the latent-resolution stand-in for 16-frame windows with stride 4):
+    registration-chained initialisation from the windows' own cameras, then 60 iterations; checked against the autograd oracle
+    evaluated at the same parameters, and for actually aligning the clip."""
+    from geo4d_amd.align import GroupAligner
+    from oracle import align as oalign
+    sc_ = _scene28()
+    groups, preds, confs, trajs, f, n, S, H, W = (sc_[k] for k in ("groups", "preds", "confs", "trajs", "f", "n", "S", "H", "W"))
     a = GroupAligner(groups, torch.stack(preds).to(dev), torch.stack(confs).to(dev), temporal_smoothing_weight=0.015, translation_weight=1.0)
     a.init_from_group(torch.stack(trajs).to(dev))
     loss0, grads = a.loss_and_grads()
@@ -313,3 +321,74 @@ def test_post_optimization_consumes_the_gathered_clip(dev):
     K[:, 0, 0], K[:, 1, 1] = 41.0, 43.0
     fixed = post_optimization(slices, maps.to(dev), traj.to(dev), dict(n_iter=12, pose_schedule="linear"), intrinsics=K, depth_traj_start_iter=6)
     assert abs(float(fixed.get_focals()[0]) - 42.0) < 1e-3, float(fixed.get_focals()[0])
+
+
+def test_sharded_residual_kernel_sums_to_the_full_objective(fix, dev):
+    """geo4d_amd/align_dist.py on the device: two emulated ranks (window blocks, restricted slot lists, pose-only terms on rank 0, no
+    process group: the all-reduce is replaced by adding the two ranks' packed buffers) reproduce the un-sharded loss and EVERY gradient
+    of the full objective (point maps + inverse depth + trajectory + smoothing) at the reference loop's end point; the depth-map
+    gradient of an image that one rank owns alone is complete on that rank; the sharded start-up fits only its own windows."""
+    from geo4d_amd.align_dist import AlignShard
+    d = fix["depth_traj"]
+    full = _late_aligner(fix, dev, "after")
+    full.set_state(d["invalid_depth_groups"], d["valid_traj_groups"])
+    loss, grads = full.loss_and_grads()
+    n = full.n
+    parts = []
+    for r in range(2):
+        sh = AlignShard(fix["groups"], n, rank=r, world=2)
+        sh._all_reduce = lambda t: t                         # no process group here: ranks are summed by hand below
+        a = _late_aligner(fix, dev, "after", shard=sh)
+        a.set_state(d["invalid_depth_groups"], d["valid_traj_groups"])
+        l, g = a.loss_and_grads()
+        parts.append((sh, float(l), {k: v.clone() for k, v in g.items()}))
+    sh0, sh1 = parts[0][0], parts[1][0]
+    assert sh0.local_groups + sh1.local_groups == list(range(len(fix["groups"]))) and sh0.shared == sh1.shared and len(sh0.shared) > 0
+    assert abs(parts[0][1] + parts[1][1] - float(loss)) < 1e-5 * abs(float(loss))
+    for k in grads:
+        tot = parts[0][2][k] + parts[1][2][k]
+        assert rel(tot, grads[k]) < 2e-5, (k, rel(tot, grads[k]))
+    only0 = [i for i in range(n) if sh0.owner[i] == 0 and i not in sh0.shared]
+    only1 = [i for i in range(n) if sh0.owner[i] == 1 and i not in sh0.shared]
+    assert only0 and only1
+    assert rel(parts[0][2]["im_depthmaps"][only0], grads["im_depthmaps"][only0]) < 2e-5 and float(parts[1][2]["im_depthmaps"][only0].abs().max()) == 0
+    assert rel(parts[1][2]["im_depthmaps"][only1], grads["im_depthmaps"][only1]) < 2e-5
+    # start-up: each emulated rank fits ITS windows; merged (s, t) table == the un-sharded fit
+    su = d["startup"]
+    ref = _late_aligner(fix, dev, su["at_start"])
+    ref.start_depth_traj()
+    tabs = []
+    for r in range(2):
+        sh = AlignShard(fix["groups"], n, rank=r, world=2)
+        sh._all_reduce = lambda t: t
+        sh.merge_rows = (lambda table, rows, _sh=sh: table * torch.zeros(table.shape[0], 1, device=table.device).index_fill_(0, torch.tensor(list(rows), device=table.device), 1.0))
+        a = _late_aligner(fix, dev, su["at_start"], shard=sh)
+        a._set_st_depth()
+        tabs.append(torch.cat([a.P["s_depth"], a.P["t_depth"]], 1).clone())
+    merged = tabs[0] + tabs[1]
+    assert (merged - torch.cat([ref.P["s_depth"], ref.P["t_depth"]], 1)).abs().max() < 1e-6
+
+
+def test_pnp_initialisation_follows_the_reference_recipe(dev):
+    """init_from_group(pose_init="pnp"): align_group's recipe (init_im_poses.py:82-214) with the seeded RANSAC-PnP of geo4d_amd/pnp.py -
+    chained clouds, one PnP per image at the ray-map focal -/+ 3 % of the image size, shared focal = mean. On the synthetic 28-frame
+    scene the cameras come out at the ground truth (up to the first window's frame and scale) and the start is as good as the
+    Pluecker-camera start."""
+    from geo4d_amd.align import GroupAligner
+    sc_ = _scene28()
+    groups, preds, confs, trajs, c2w, f, n, H, W = (sc_[k] for k in ("groups", "preds", "confs", "trajs", "c2w", "f", "n", "H", "W"))
+    raymaps = sc_["rays"].expand(len(groups), sc_["S"], H, W, 3)
+    a = GroupAligner(groups, torch.stack(preds).to(dev), torch.stack(confs).to(dev), temporal_smoothing_weight=0.015, translation_weight=1.0)
+    a.init_from_group(None, raymaps=raymaps.to(dev), pose_init="pnp", niter_PnP=50)
+    b = GroupAligner(groups, torch.stack(preds).to(dev), torch.stack(confs).to(dev), temporal_smoothing_weight=0.015, translation_weight=1.0)
+    b.init_from_group(torch.stack(trajs).to(dev), raymaps=raymaps.to(dev))
+    la, lb = float(a.loss_and_grads()[0]), float(b.loss_and_grads()[0])
+    M = a.get_im_poses_matrix().cpu()
+    w2c0 = torch.inverse(c2w[groups[0][0]])
+    scale = float(M[5, :3, 3].norm() / (w2c0 @ c2w[5])[:3, 3].norm())                 # the world is window 0's frame at the normalised scale
+    rot_err = max(float((M[i, :3, :3] - (w2c0 @ c2w[i])[:3, :3]).abs().max()) for i in range(n))
+    tr_err = max(float((M[i, :3, 3] / scale - (w2c0 @ c2w[i])[:3, 3]).abs().max()) for i in range(n))
+    print(f"[pnp init] loss {la:.5f} (trajectory-based start {lb:.5f}); focal {float(a.get_focals()[0]):.2f} (true {f}); max rotation entry error {rot_err:.2e}, translation {tr_err:.2e}")
+    assert la < 0.05 and la < 2.0 * lb + 1e-3 and abs(float(a.get_focals()[0]) - f) < 0.05 * f
+    assert rot_err < 2e-2 and tr_err < 5e-2
+    assert a.init_focals.shape == (n,) and float((a.init_focals - f).abs().max()) < 0.06 * f

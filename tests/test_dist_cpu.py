@@ -136,3 +136,113 @@ def test_bench_self_launches_n_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True,
                         text=True, timeout=120)
     assert r2.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in (r2.stdout + r2.stderr)
+
+
+# ---- alignment sharded over ranks (geo4d_amd/align_dist.py; north_star: "point-map alignment shard over the 8 GPUs") ------------------
+def _align_problem(n=11, S=4, H=6, W=8, seed=3):
+    """A small multi-window alignment problem in the oracle's format: windows of S consecutive images, stride 1 (overlapping)."""
+    g = torch.Generator().manual_seed(seed)
+    groups = [list(range(s, s + S)) for s in range(0, n - S + 1)]
+    G, HW = len(groups), H * W
+    data = dict(pred=torch.randn((G * S, HW, 3), generator=g) + torch.tensor([0.0, 0.0, 3.0]), conf=torch.rand((G * S, HW), generator=g) * 12,
+                e_all=torch.tensor([i for grp in groups for i in grp]), H=H, W=W,
+                invdepth=torch.rand((G * S, HW), generator=g), traj=torch.eye(4).repeat(G * S, 1, 1) + 0.01 * torch.randn((G * S, 4, 4), generator=g))
+    P = dict(im_depthmaps=0.3 * torch.randn((n, HW), generator=g) + 1.0,
+             im_poses=torch.cat([0.1 * torch.randn((n, 3), generator=g), torch.ones(n, 1), 0.2 * torch.randn((n, 3), generator=g)], 1),
+             im_focals=torch.full((1, 1), 20.0 * 2.2), pw_poses=torch.cat([0.1 * torch.randn((G, 3), generator=g), torch.ones(G, 1), 0.1 * torch.randn((G, 4), generator=g)], 1),
+             s_depth=torch.ones(G, 1) + 0.1 * torch.randn((G, 1), generator=g), t_depth=0.05 * torch.randn((G, 1), generator=g),
+             traj_align_poses=torch.cat([0.05 * torch.randn((G, 3), generator=g), torch.ones(G, 1), 0.05 * torch.randn((G, 4), generator=g)], 1))
+    state = dict(invalid_depth_groups=[1], valid_traj_groups=[0, 2, G - 1])
+    return groups, data, P, state
+
+
+def _adam_run(P, objective, niter=8, lr=0.02):
+    """torch.optim.Adam arithmetic (betas 0.9 / 0.9) on a dict of tensors with externally supplied gradients."""
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    losses = []
+    for it in range(1, niter + 1):
+        loss, grads = objective(P)
+        losses.append(float(loss))
+        for k in P:
+            m[k].mul_(0.9).add_(grads[k], alpha=0.1)
+            v2[k].mul_(0.9).addcmul_(grads[k], grads[k], value=0.1)
+            P[k] = P[k] - lr / (1 - 0.9 ** it) * m[k] / ((v2[k] / (1 - 0.9 ** it)).sqrt() + 1e-8)
+    return losses
+
+
+def _oracle_objective(data, state, local_groups=None, pose_terms=True):
+    from oracle import align as oalign
+
+    def f(P):
+        Q = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+        loss = oalign.alignment_loss(Q, data, temporal_smoothing_weight=0.015, translation_weight=1.0, state=state, local_groups=local_groups,
+                                     pose_terms=pose_terms)
+        loss.backward()
+        return loss.detach(), {k: (q.grad if q.grad is not None else torch.zeros_like(q)) for k, q in Q.items()}
+    return f
+
+
+def _align_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from geo4d_amd import dist as gd
+    from geo4d_amd.align_dist import AlignShard
+    gd.init_from_env(backend="gloo")
+    groups, data, P, state = _align_problem()
+    shard = AlignShard(groups, P["im_depthmaps"].shape[0])
+    local = _oracle_objective(data, state, local_groups=shard.local_groups, pose_terms=shard.primary)
+    first = {}
+
+    def objective(Pc):
+        loss, grads = shard.reduce(*local(Pc))
+        if not first:
+            first.update(loss=float(loss), grads={k: v.clone() for k, v in grads.items()})
+        return loss, grads
+    losses = _adam_run(P, objective)
+    P["im_depthmaps"] = shard.gather_depthmaps(P["im_depthmaps"])
+    tab = shard.merge_rows(torch.arange(len(groups) * 3, dtype=torch.float32).reshape(-1, 3) + 1, shard.local_groups)
+    # plain numpy through the queue (torch's shared-memory tensor hand-off dies with the worker)
+    first["grads"] = {k: v.numpy().copy() for k, v in first["grads"].items()}
+    q.put((rank, shard.local_groups, shard.shared, first, losses, {k: v.detach().numpy().copy() for k, v in P.items()}, tab.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_alignment_sharded_over_two_ranks_equals_single_rank():
+    """Window blocks on 2 ranks, one all-reduce of [loss | small gradients | depth gradients of the shared images] per iteration:
+    the first loss / gradients and 8 Adam iterations equal the un-sharded objective to fp32 round-off; depth maps of images that only
+    one rank touches are final on that rank alone and assembled by gather_depthmaps."""
+    from geo4d_amd.align_dist import AlignShard, partition_windows
+    assert [partition_windows(30, r, 8) for r in range(8)][0] == [0, 1, 2, 3] and sum(len(partition_windows(30, r, 8)) for r in range(8)) == 30
+    s8 = AlignShard([list(range(4 * w, 4 * w + 16)) for w in range(29)], 128, rank=3, world=8)
+    assert len(s8.shared) == 7 * 12 and s8.local_groups == partition_windows(29, 3, 8)      # 12 images per block boundary
+    groups, data, P, state = _align_problem()
+    ref_obj = _oracle_objective(data, state)
+    ref_loss, ref_grads = ref_obj(P)
+    ref_P = {k: v.clone() for k, v in P.items()}
+    ref_losses = _adam_run(ref_P, ref_obj)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_align_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    [p.join(timeout=60) for p in procs]
+    res = [(r, lg, sh, dict(loss=f["loss"], grads={k: torch.from_numpy(v) for k, v in f["grads"].items()}), ls,
+            {k: torch.from_numpy(v) for k, v in Pr.items()}, torch.from_numpy(tab)) for r, lg, sh, f, ls, Pr, tab in res]
+    n = P["im_depthmaps"].shape[0]
+    assert res[0][1] + res[1][1] == list(range(len(groups))) and res[0][2] == res[1][2] and 0 < len(res[0][2]) < n
+    shared = res[0][2]
+    for rank, local, _, first, losses, Pr, tab in res:
+        assert abs(first["loss"] - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+        for k, gref in ref_grads.items():
+            if k == "im_depthmaps":      # complete on every rank for the shared images, complete on the owning rank for the others
+                assert torch.allclose(first["grads"][k][shared], gref[shared], rtol=1e-4, atol=1e-7), k
+            else:
+                assert torch.allclose(first["grads"][k], gref, rtol=1e-4, atol=1e-7), k
+        assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 1e-5 * abs(ref_losses[0])
+        for k, v in ref_P.items():
+            assert torch.allclose(Pr[k], v, rtol=2e-4, atol=2e-6), (rank, k, (Pr[k] - v).abs().max())
+        assert torch.equal(tab, torch.arange(len(groups) * 3, dtype=torch.float32).reshape(-1, 3) + 1)
+    for k in ref_P:                          # the replicated parameters are bit-identical across ranks (no broadcast needed)
+        assert torch.equal(res[0][5][k], res[1][5][k]), k

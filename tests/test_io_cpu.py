@@ -55,3 +55,43 @@ def test_writers_formats(tmp_path):
     assert np.allclose(np.load(tmp_path / "frame_0002.npy"), depth[2].numpy())
     for n in ("frame_colordepth_0000.png", "colored_depth_maps.gif", "conf_1.npy"):
         assert os.path.getsize(tmp_path / n) > 0
+
+
+def test_glb_export_is_a_valid_binary_gltf(tmp_path):
+    """save_glb (dust3r/utils/viz_demo.py:13-58, as_pointcloud=True): container layout, chunk sizes, accessor counts / bounds, the
+    reference's scene transform, and the point / colour payload read back bit for bit."""
+    import json
+    import struct
+    import numpy as np
+    from geo4d_amd import io as gio
+    rng = np.random.default_rng(0)
+    n, H, W = 3, 6, 8
+    imgs, pts = rng.uniform(size=(n, H, W, 3)).astype(np.float32), rng.normal(size=(n, H, W, 3)).astype(np.float32)
+    masks = rng.uniform(size=(n, H, W)) > 0.3
+    c2w = np.tile(np.eye(4), (n, 1, 1))
+    c2w[:, :3, 3] = rng.normal(size=(n, 3))
+    th = 0.3
+    c2w[0, :3, :3] = [[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]]
+    path = gio.save_glb(str(tmp_path / "scene.glb"), torch.from_numpy(imgs), torch.from_numpy(pts), masks, np.full(n, 50.0), c2w)
+    raw = open(path, "rb").read()
+    magic, version, total = struct.unpack("<4sII", raw[:12])
+    assert magic == b"glTF" and version == 2 and total == len(raw)
+    jlen, jtype = struct.unpack("<I4s", raw[12:20])
+    doc = json.loads(raw[20:20 + jlen])
+    blen, btype = struct.unpack("<I4s", raw[20 + jlen:28 + jlen])
+    assert jtype == b"JSON" and btype == b"BIN\x00" and jlen % 4 == 0 and 28 + jlen + blen == total and doc["buffers"][0]["byteLength"] == blen
+    assert len(doc["meshes"]) == 1 + n and doc["meshes"][0]["primitives"][0]["mode"] == 0 and all(m["primitives"][0]["mode"] == 1 for m in doc["meshes"][1:])
+    binbuf = raw[28 + jlen:]
+    acc = doc["accessors"][doc["meshes"][0]["primitives"][0]["attributes"]["POSITION"]]
+    view = doc["bufferViews"][acc["bufferView"]]
+    got = np.frombuffer(binbuf[view["byteOffset"]:view["byteOffset"] + view["byteLength"]], np.float32).reshape(-1, 3)
+    want = np.concatenate([p[m] for p, m in zip(pts, masks)])
+    assert acc["count"] == int(masks.sum()) and np.array_equal(got, want) and np.allclose(acc["min"], want.min(0)) and np.allclose(acc["max"], want.max(0))
+    cacc = doc["accessors"][doc["meshes"][0]["primitives"][0]["attributes"]["COLOR_0"]]
+    cview = doc["bufferViews"][cacc["bufferView"]]
+    cols = np.frombuffer(binbuf[cview["byteOffset"]:cview["byteOffset"] + cview["byteLength"]], np.uint8).reshape(-1, 4)
+    assert cacc["normalized"] and np.abs(cols[:, :3].astype(np.float32) / 255 - np.concatenate([im[m] for im, m in zip(imgs, masks)])).max() < 0.5 / 255 + 1e-6
+    assert all(doc["accessors"][m["primitives"][0]["attributes"]["POSITION"]]["count"] == 16 for m in doc["meshes"][1:])      # 8 edges per camera
+    rot = np.diag([-1.0, 1.0, -1.0, 1.0])
+    M = np.array(doc["nodes"][0]["matrix"]).reshape(4, 4).T
+    assert np.allclose(M, np.linalg.inv(c2w[0] @ gio.OPENGL @ rot)) and all(nd["matrix"] == doc["nodes"][0]["matrix"] for nd in doc["nodes"])
