@@ -446,7 +446,7 @@ class GroupAligner:
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
-                        with torch.cuda.graph(g, stream=side):
+                        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                             iteration()
                     torch.cuda.current_stream().wait_stream(side)
                     for _ in range(count - 1):          # capturing records, it does not run

@@ -121,9 +121,11 @@ class DDIMSampler(object):
         window's result does not depend on what ran before it; ``strict_rng`` — draw one ``randn`` per step even at eta == 0
         like ``noise_like`` in ddim.py:271 does (keeps the global RNG stream aligned with the reference across calls; forces
         the eager path). ``precision`` is accepted and ignored (the compute mode is a property of the model here)."""
-        if mask is not None or x0 is not None or score_corrector is not None or quantize_x0 or noise_dropout > 0.:
-            raise NotImplementedError("mask / x0 / score_corrector / quantize_x0 / noise_dropout are not used by Geo4D "
+        if score_corrector is not None or quantize_x0 or noise_dropout > 0.:
+            raise NotImplementedError("score_corrector / quantize_x0 / noise_dropout are not used by Geo4D "
                                       "inference (test_geo4d.py:212-227) and have no HIP path")
+        if (mask is None) != (x0 is None):
+            raise ValueError("mask and x0 go together (ddim.py:174-175)")
         if self.model.parameterization != "v":
             raise NotImplementedError("only the v-parameterisation of configs/inference_geo4d.yaml:43 is built")
         gen = kwargs.pop("noise_generator", None)
@@ -133,8 +135,9 @@ class DDIMSampler(object):
         dev = self.model.device
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         total = len(self.ddim_timesteps)
-        kwargs.pop("clean_cond", None)
-        graph_ok = (self.use_graph and eta == 0. and not strict_rng and callback is None and img_callback is None and total > 2)
+        clean_cond = bool(kwargs.pop("clean_cond", False))
+        graph_ok = (self.use_graph and eta == 0. and not strict_rng and callback is None and img_callback is None and total > 2
+                    and mask is None)
         # 3-way guidance of ddim_multiplecond.py:229-234 (image yes / text "" as a third evaluation)
         uc_img = kwargs.get("unconditional_conditioning_img_nonetext") if (self.multicond and cfg) else None
         if self.multicond and cfg and uc_img is None:
@@ -213,7 +216,8 @@ class DDIMSampler(object):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
+                # thread_local: a process-group watchdog thread (N > 1: RCCL) may query its events while this thread captures
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     step()                           # recorded, not executed
             torch.cuda.current_stream().wait_stream(side)
             for i in range(1, total):
@@ -224,6 +228,12 @@ class DDIMSampler(object):
             self._static, self._graph_key = st, key
         else:
             for i in range(total):
+                if mask is not None:
+                    # ddim.py:173-180: blend the (noised) original latent back in before every step - inpainting-style sampling
+                    t_now = torch.full((batch_size,), int(self.ddim_timesteps[total - 1 - i]), device=dev, dtype=torch.long)
+                    x0d, md = x0.to(dev).float(), mask.to(dev).float()
+                    img_orig = x0d if clean_cond else self.model.q_sample(x0d, t_now, noise=torch.randn(x0d.shape, device=dev, generator=gen))
+                    img.copy_(img_orig * md + (1. - md) * img)
                 noise = None
                 if eta > 0.:
                     noise = torch.randn(size, device=dev, generator=gen) * temperature

@@ -98,6 +98,11 @@ class LatentDiffusion(nn.Module):
     def predict_eps_from_z_and_v(self, x_t, t, v):
         return self._gather(self.sqrt_alphas_cumprod, t, x_t) * v + self._gather(self.sqrt_one_minus_alphas_cumprod, t, x_t) * x_t
 
+    def q_sample(self, x_start, t, noise=None):
+        """ddpm3d.py:344-355: the forward process at step t (used by the samplers' mask / x0 blending)."""
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return self._gather(self.sqrt_alphas_cumprod, t, x_start) * x_start + self._gather(self.sqrt_one_minus_alphas_cumprod, t, x_start) * noise
+
     # ---- denoiser (ddpm3d.py:1002-1017) -------------------------------------------------------------------------------
     def apply_model(self, x_noisy, t, cond, **kwargs):
         if not isinstance(cond, dict):

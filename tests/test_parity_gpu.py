@@ -157,6 +157,28 @@ def test_ddim_sampler_vs_reference_golden(dev, mode, tol, graph):
     assert ray.shape == g["decode_first_stage_4_8"].shape and e2 < max(tol, 2e-4) * 2
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16x3", 2e-4)])
+def test_ddim_mask_blending_vs_reference_golden(dev, mode, tol):
+    """mask / x0 (ddim.py:173-180, clean_cond): golden = the reference DDIMSampler on the tiny LatentDiffusion (generate.py ddim_mask).
+    The masked region ends one step away from x0, the rest is sampled; an all-zero mask reproduces the unmasked sampler bit for bit."""
+    from geo4d_amd.ddim import DDIMSampler
+    g = load("ddim_mask_tiny.pt")
+    m, _, _ = _diffusion(dev, mode)
+    cond = {"c_crossattn": [g["context"].to(dev)], "c_concat": [g["c_concat"].to(dev)]}
+    kw = dict(S=g["S"], conditioning=cond, batch_size=1, shape=list(g["x_T"].shape[1:]), verbose=False, unconditional_guidance_scale=1.0,
+              unconditional_conditioning=None, eta=0.0, cfg_img=None, fs=g["fs"].to(dev), x_T=g["x_T"].to(dev),
+              timestep_spacing="uniform_trailing", guidance_rescale=0.7, unconditional_conditioning_img_nonetext=None)
+    out, _ = DDIMSampler(m).sample(mask=g["mask"].to(dev), x0=g["x0"].to(dev), clean_cond=True, **kw)
+    e = rel(out, g["samples"])
+    print(f"[ddim mask] mode={mode} rel_l2 vs reference = {e:.3e}")
+    assert e < tol
+    plain, _ = DDIMSampler(m, use_graph=False).sample(**kw)
+    zero, _ = DDIMSampler(m).sample(mask=torch.zeros_like(g["mask"]).to(dev), x0=g["x0"].to(dev), clean_cond=True, **kw)
+    assert torch.equal(plain, zero)
+    with pytest.raises(ValueError):
+        DDIMSampler(m).sample(mask=g["mask"].to(dev), x0=None, **kw)
+
+
 @pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("f16", 2e-2), ("bf16", 1e-1)])
 def test_window_end_to_end_vs_oracle(dev, mode, tol):
     """One window: DDIM (S=3, eta 0, uniform_trailing) + 4-modality decode, HIP vs oracle on identical inputs.

@@ -103,3 +103,25 @@ def test_vae_decode_at_576x1024_and_chunked_decode(engine, dev):
     finally:
         pipe.DECODE_PIXEL_BUDGET = old
     assert whole.shape == (3, 11, 2, 128, 192) and rel(chunked, whole) < 2e-2     # fp16: tile / split-K choice differs with the batch
+
+
+def test_full_config_at_576x1024_vs_the_reference(full_engine, dev):
+    """BASELINE configs[4]'s spatial size against the REFERENCE itself: tests/golden/hires.pt = the reference UNetModel (shipped 1.44 B
+    yaml config, name-keyed seeded weights) at x = [1,20,2,72,128] (N = 9216 tokens per frame, 2 frames so that the reference's einsum
+    attention fits a CPU run; `generate.py hires`). f32 and bf16x3 < 2e-4, f16 (the mode configs[4] names) and bf16 reported and bounded."""
+    from oracle.params import seeded_state_dict
+    ref = torch.load(os.path.join(G, "hires.pt"), weights_only=False)
+    g = torch.load(os.path.join(G, "unet_full.pt"), weights_only=False)
+    net = full_engine[0].model.diffusion_model
+    net.load_state_dict(seeded_state_dict(g["shapes"]), strict=True)
+    rn = lambda shape, seed: torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+    T = 2
+    x, ctx = rn((1, 20, T, 72, 128), 920).to(dev), rn((1, 77 + 16 * T, 1024), 921).to(dev)
+    t, fs = torch.tensor([499], device=dev), torch.tensor([24], device=dev)
+    errs = {}
+    for mode in ("f32", "bf16x3", "f16", "bf16"):
+        net.set_compute_dtype(mode)
+        errs[mode] = rel(net(x, t, context=ctx, fs=fs).cpu(), ref["unet_out"])
+    net.set_compute_dtype("bf16")
+    print("[1.44 B U-Net at 72x128 latents (N = 9216) vs reference] " + "  ".join(f"{k}: {v:.3e}" for k, v in errs.items()))
+    assert errs["f32"] < 2e-4 and errs["bf16x3"] < 2e-4 and errs["f16"] < 1e-2 and errs["bf16"] < 5e-2, errs

@@ -1,0 +1,5 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r3g; mkdir -p $O; cd $R; export TMPDIR=/tmp
+( time timeout 1500 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+grep -E "passed|failed|rc=|^FAILED|^ERROR" $O/pytest.log | tail -12
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -4 $O/smoke.log
