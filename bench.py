@@ -325,8 +325,8 @@ def main():
         x_T = torch.randn((B, 16, T, h, w), generator=torch.Generator().manual_seed(7)).to(dev)
         n_gemm, tf_gemm, ms_gemm = gemm_timeline(model, x_T, cond, fs, dev)
         traffic, traffic_note = None, "no PMC summary committed for this dtype / size"
-        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.dtype}.json")
-        if (args.height, args.width, T, B) == (320, 512, 16, 1) and os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_{args.dtype}.json") for r in (3, 2)) if os.path.exists(q)), "")
+        if (args.height, args.width, T, B) == (320, 512, 16, 1) and pmc_path:
             with open(pmc_path) as f:
                 pmc = json.load(f)["per_unet_forward"]
             traffic = pmc["fetch_bytes_x2"] + pmc["write_bytes"]
@@ -365,7 +365,7 @@ def main():
                          "note": "achieved = algorithmic flops (sum of 2*M*N*K over the conv_gemm launches of ONE eager U-Net forward, each product "
                                  "counted once) / sum of their HIP-event durations on the launch stream (brackets include a split-K launch's reduce "
                                  "kernel and ~2 us of dispatch gap each; the rocprofv3 kernel trace in profiles/ gives the pure kernel time); "
-                                 "peak = dense MFMA peak of the operand type / MFMA passes per product; measured on this GPU (profiles/r02_mfma_probe_and_kloop.md): "
+                                 "peak = dense MFMA peak of the operand type / MFMA passes per product; measured on this GPU type (profiles/r02_mfma_probe_and_kloop.md): "
                                  "a pure MFMA loop on uniform random bf16 operands reaches 0.71 of that peak, 0.64 with the LDS fragment reads of the tile",
                          "whole_step": {"achieved": achieved, "frac": passes * achieved / peak,
                                         "note": f"{tflop_step:.1f} algorithmic TFLOP per step (SURVEY §8d: {TFLOP_UNET_STEP} x S + "

@@ -47,7 +47,7 @@ class GroupNorm(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("ldx", C.c_long), ("ldy", C.c_long),
         ("F", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("frames_per_stat", C.c_int),
-        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("barrier", C.c_void_p), ("split_out", C.c_int),
+        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("barrier", C.c_void_p), ("counters", C.c_void_p), ("split_out", C.c_int),
     ]
 
 

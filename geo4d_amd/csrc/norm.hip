@@ -140,6 +140,41 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// ---- GroupNorm pass 1 + 2 in ONE launch: every workgroup writes its partial, takes a ticket on its statistic's counter, and the LAST
+// arriver of a statistic (frames_per_stat x nchunk tickets) merges that statistic's partials - the same fixed-order merge as
+// gn_finalize_kernel, so the result is bit-identical - and clears the counter for the next GroupNorm. Nobody waits (no co-residency
+// requirement, unlike a grid barrier): release before the ticket, acquire in the last arriver (cdna_hip_programming.md Guideline 16).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_last_kernel(const T* __restrict__ x, long ldx, int HW, int C, int G, int R, int nchunk,
+                                                              int fps, float eps, float* __restrict__ part, float* __restrict__ stats,
+                                                              unsigned int* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.y, stat = f / fps;
+    gn_partial_body<T>(smem, x, ldx, HW, C, G, R, nchunk, part, blockIdx.x, f);
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int ticket = __hip_atomic_fetch_add(counters + stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = ticket == (unsigned int)(fps * nchunk - 1);
+        if (is_last) {
+            __hip_atomic_store(counters + stat, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (int grp = wave; grp < G; grp += 4) {
+        const f32x2 r = gn_merge_unit(part, fps * nchunk, stat, grp, G, eps, lane);
+        if (lane == 0) {
+            stats[((long)stat * G + grp) * 2 + 0] = r[0];
+            stats[((long)stat * G + grp) * 2 + 1] = r[1];
+        }
+    }
+}
+
 // ---- GroupNorm pass 2': the same merge fed by the column sums the producing conv_gemm's epilogue wrote (gn_colsum): one item
 // per (32-row block, channel of the group) = (n = 32, mean = s / 32, M2 = q - s * mean); replaces pass 1 + pass 2 ----------------
 __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __restrict__ colsum, int blocks_per_stat, int C, int G, float eps,
@@ -411,12 +446,18 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
                            p.C, p.groups, p.eps, stats, nstat);
         GEO4D_CHECK_LAUNCH();
     } else {
-        hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
-                           R, nchunk, part);
-        GEO4D_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
-                           p.groups, p.eps, stats, nstat);
-        GEO4D_CHECK_LAUNCH();
+        if (p.counters && nstat <= 1024) {       // statistics + merge by the last arriver: two launches per GroupNorm instead of three
+            hipLaunchKernelGGL(gn_partial_last_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
+                               R, nchunk, p.frames_per_stat, p.eps, part, stats, (unsigned int*)p.counters);
+            GEO4D_CHECK_LAUNCH();
+        } else {
+            hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
+                               R, nchunk, part);
+            GEO4D_CHECK_LAUNCH();
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
+                               p.groups, p.eps, stats, nstat);
+            GEO4D_CHECK_LAUNCH();
+        }
     }
     hipLaunchKernelGGL((gn_apply_kernel<T, SPLIT>), dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
                        p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act);
@@ -466,6 +507,7 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
     if (p.colsum && ((p.HW % 32) || ((uintptr_t)p.colsum % 8))) { geo4d_set_error("groupnorm: colsum needs HW % 32 == 0"); return GEO4D_EINVAL; }
     if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8))) { geo4d_set_error("groupnorm: split_out is the bf16x3 producer format: f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
     if (p.barrier && ((uintptr_t)p.barrier % 8)) { geo4d_set_error("groupnorm: barrier alignment"); return GEO4D_EINVAL; }
+    if (p.counters && ((uintptr_t)p.counters % 4)) { geo4d_set_error("groupnorm: counters alignment"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {
         case GEO4D_F32: return p.split_out ? groupnorm_typed<float, true>(p, s) : groupnorm_typed<float, false>(p, s);

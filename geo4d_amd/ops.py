@@ -314,6 +314,7 @@ _gn_ws = {}
 
 
 GN_ONE_LAUNCH = _os.environ.get("GEO4D_GN_ONE_LAUNCH", "0") != "0"   # statistics + merge + apply around a grid-wide barrier (norm.hip)
+GN_TWO_LAUNCH = _os.environ.get("GEO4D_GN_TWO_LAUNCH", "0") != "0"   # statistics launch whose last-arriving workgroup merges (measured slower: per-workgroup agent-scope release)
 _gn_barrier = {}
 
 
@@ -322,7 +323,7 @@ def gn_barrier(device):
     Allocated on first use outside graph capture (callers warm up eagerly before capturing)."""
     b = _gn_barrier.get(device)
     if b is None:
-        b = _gn_barrier[device] = torch.zeros(2, device=device, dtype=torch.int32)
+        b = _gn_barrier[device] = torch.zeros(2 + 1024, device=device, dtype=torch.int32)     # barrier pair + 1024 ticket counters
     return b
 
 
@@ -345,6 +346,7 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     p.ldx, p.ldy = _ld(x), (_ld(out) // 2 if split_out else _ld(out))
     p.split_out = int(split_out)
     p.barrier = gn_barrier(x.device).data_ptr() if GN_ONE_LAUNCH else 0
+    p.counters = gn_barrier(x.device).data_ptr() + 8 if GN_TWO_LAUNCH else 0
     p.F, p.HW, p.C, p.groups, p.frames_per_stat = F, HW, Cc, groups, frames_per_stat
     p.act, p.dtype, p.eps = int(silu), dt_code(x.dtype), eps
     cs = getattr(x, "_gn_colsum", None)     # column sums left on this very tensor object by the GEMM that produced it

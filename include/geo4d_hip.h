@@ -100,6 +100,9 @@ typedef struct geo4d_groupnorm_t {
     void* barrier;       /* optional: 8 bytes of persistent, zero-initialised device memory (one GroupNorm at a time per buffer, i.e.
                             stream-ordered use). When given and every workgroup can be resident, statistics + merge + apply run as ONE
                             launch around a grid-wide barrier (bit-identical to the three-launch path); NULL = three launches */
+    void* counters;      /* optional: 4 KiB of persistent, zero-initialised device memory (1024 ticket counters, one per statistic; stream-
+                            ordered use). When given, the statistics launch also merges them (the last workgroup to arrive at a
+                            statistic's counter does it and clears the counter): two launches instead of three, bit-identical */
     int split_out;       /* bf16x3 producers (dtype F32 only, C % 8 == 0): y is written in the PRE-SPLIT operand format of
                             geo4d_conv_gemm_t.a_split - per 8 channels [8 x bf16 hi | 8 x bf16 lo]; ldy still counts channels */
 } geo4d_groupnorm_t;

@@ -46,15 +46,21 @@ def test_groupnorm_split_output_and_one_launch(dev, case):
     F, HW, C, fps, silu = case
     x = rnd((F * HW, C), dev, 1) * 2 + 0.5
     g, b = rnd((C,), dev, 2) + 1, rnd((C,), dev, 3)
-    ops.GN_ONE_LAUNCH = False
+    one, two = ops.GN_ONE_LAUNCH, ops.GN_TWO_LAUNCH
+    ops.GN_ONE_LAUNCH = ops.GN_TWO_LAUNCH = False
     try:
         y3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
         s3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
-    finally:
+        ops.GN_TWO_LAUNCH = True
+        y2 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
+        y2b = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)      # the ticket counters reset themselves
         ops.GN_ONE_LAUNCH = True
-    y1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
-    y1b = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)          # the barrier resets itself
-    s1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
+        y1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
+        y1b = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)      # the barrier resets itself
+        s1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
+    finally:
+        ops.GN_ONE_LAUNCH, ops.GN_TWO_LAUNCH = one, two
+    assert torch.equal(y2, y3) and torch.equal(y2, y2b), "two-launch GroupNorm (last arriver merges) differs from the three-launch path"
     assert torch.equal(y1, y3) and torch.equal(y1, y1b), "one-launch GroupNorm differs from the three-launch path"
     assert torch.equal(s1.as_subclass(torch.Tensor), s3.as_subclass(torch.Tensor))
     ref = TF.group_norm(x.reshape(F // fps, fps * HW, C).permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1).reshape(F * HW, C)
@@ -72,8 +78,13 @@ def test_groupnorm_one_launch_many_in_a_row_and_big_grid(dev):
     x = rnd((F * HW, C), dev, 5)
     g, b = rnd((C,), dev, 6) + 1, rnd((C,), dev, 7)
     outs = [ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-6, silu=True) for _ in range(6)]
+    ops.GN_ONE_LAUNCH = True
+    try:
+        outs += [ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-6, silu=True) for _ in range(3)]
+    finally:
+        ops.GN_ONE_LAUNCH = False
     torch.cuda.synchronize()
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert all(((outs[0] - o).abs().max() < 1e-5) for o in outs[1:]) and all(torch.equal(outs[0], o) for o in outs[1:6])
     ref = TF.silu(TF.group_norm(x.reshape(F, HW, C).permute(0, 2, 1), 32, g, b, 1e-6).permute(0, 2, 1).reshape(F * HW, C))
     assert ((outs[0] - ref).norm() / ref.norm()).item() < 2e-5
 
