@@ -324,12 +324,13 @@ def main():
         passes = MFMA_PASSES[args.dtype]
         x_T = torch.randn((B, 16, T, h, w), generator=torch.Generator().manual_seed(7)).to(dev)
         n_gemm, tf_gemm, ms_gemm = gemm_timeline(model, x_T, cond, fs, dev)
-        traffic, traffic_note = None, "no PMC summary committed for this dtype / size"
+        traffic, traffic_note, traffic_by_class = None, "no PMC summary committed for this dtype / size", None
         pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_{args.dtype}.json") for r in (3, 2)) if os.path.exists(q)), "")
         if (args.height, args.width, T, B) == (320, 512, 16, 1) and pmc_path:
             with open(pmc_path) as f:
                 pmc = json.load(f)["per_unet_forward"]
             traffic = pmc["fetch_bytes_x2"] + pmc["write_bytes"]
+            traffic_by_class = pmc.get("by_class")
             traffic_note = ("L2-miss (fabric-side) bytes of ONE U-Net forward, ALL its kernels: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from "
                             f"separate rocprofv3 --pmc passes ({os.path.basename(pmc_path)}; Infinity-Cache hits included: upper bound on HBM bytes)")
         cfg_name = "BASELINE.json configs[1]" if (args.height, args.width, T, B) == (320, 512, 16, 1) else \
@@ -362,6 +363,7 @@ def main():
                          "launches_per_unet_forward": n_gemm, "tflop_per_unet_forward": tf_gemm, "ms_per_unet_forward": ms_gemm,
                          "avg_launch_us": 1e3 * ms_gemm / n_gemm,
                          "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_by_kernel_class_gb": traffic_by_class,      # the same PMC passes split by kernel class (GB per U-Net forward)
                          "note": "achieved = algorithmic flops (sum of 2*M*N*K over the conv_gemm launches of ONE eager U-Net forward, each product "
                                  "counted once) / sum of their HIP-event durations on the launch stream (brackets include a split-K launch's reduce "
                                  "kernel and ~2 us of dispatch gap each; the rocprofv3 kernel trace in profiles/ gives the pure kernel time); "
