@@ -233,6 +233,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         cs = torch.empty((M // 32, N, 2), device=out.device, dtype=torch.float32)
         p.gn_colsum = cs.data_ptr()
         out._gn_colsum = cs
+        out._gn_colsum_tag = (out.data_ptr(), out._version)      # groupnorm() ignores the sums if the buffer was rewritten by torch since
     if GEMM_TIMELINE is not None:     # bench.py's per-launch HIP-event timeline of the dominant kernel (never on while capturing)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -350,6 +351,8 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     p.F, p.HW, p.C, p.groups, p.frames_per_stat = F, HW, Cc, groups, frames_per_stat
     p.act, p.dtype, p.eps = int(silu), dt_code(x.dtype), eps
     cs = getattr(x, "_gn_colsum", None)     # column sums left on this very tensor object by the GEMM that produced it
+    if cs is not None and getattr(x, "_gn_colsum_tag", None) != (x.data_ptr(), x._version):
+        cs = None                            # the tensor was modified in place (or re-viewed) after the GEMM wrote it: stale sums
     p.colsum = cs.data_ptr() if (cs is not None and HW % 32 == 0 and tuple(cs.shape) == (F * HW // 32, Cc, 2)) else 0
     _lib.check(lib.geo4d_groupnorm(C.byref(p), _stream()), "geo4d_groupnorm")
     return out

@@ -35,9 +35,19 @@ def dev():
 
 
 @pytest.fixture(scope="session")
-def full_engine(dev):
-    """ONE instance of the shipped 1.44 B-parameter configuration (+ both VAEs) shared by every full-size test: building it
-    costs tens of seconds of host time. Tests switch its compute mode with set_mode() and must not rely on its weights."""
+def _full_engine_session(dev):
     import bench
-    model, pvae = bench.build("bf16", dev)
-    return model, pvae
+    return bench.build("bf16", dev)
+
+
+@pytest.fixture
+def full_engine(_full_engine_session):
+    """ONE instance of the shipped 1.44 B-parameter configuration (+ both VAEs) shared by every full-size test: building it costs
+    tens of seconds of host time. Every test gets it in the bf16 mode and it is put back into bf16 afterwards, so the MODE never
+    depends on collection order; the WEIGHTS do (re-filling 1.44 B parameters per test costs more than the tests): a test that
+    compares against a fixture loads the name-keyed seeded weights itself, the others only use engine-vs-engine properties."""
+    import bench
+    model, pvae = _full_engine_session
+    bench.set_mode(model, pvae, "bf16")
+    yield model, pvae
+    bench.set_mode(model, pvae, "bf16")

@@ -45,7 +45,7 @@ def test_unet_tiny_config_at_sintel_window_size_vs_oracle(dev):
     assert errs["f32"] < 2e-4 and errs["bf16x3"] < 2e-4 and errs["f16"] < 1e-2 and errs["bf16"] < 5e-2, errs
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def engine(dev, full_engine):
     import bench
     bench.set_mode(*full_engine, "f16")
