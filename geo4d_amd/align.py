@@ -568,7 +568,7 @@ def _init_pnp(self, pred, conf, focal, raymaps, niter_PnP, seed):
 
     def run_pnp(i, g, k):
         msk = (conf[g, k] > 0.5).reshape(H, W).cpu().numpy()
-        return pnp.fast_pnp(pts3d[i].reshape(H, W, 3).double().cpu().numpy(), im_focals[i], msk, niter_PnP=niter_PnP, seed=seed + i)
+        return pnp.fast_pnp(pts3d[i].reshape(H, W, 3).double().cpu().numpy(), im_focals[i], msk, niter_PnP=niter_PnP, seed=seed)
     done = set()
     for k, i in enumerate(self.groups[0]):                                  # the first window is the world frame
         pts3d[i], conf_list[i] = pred[0, k].clone(), conf[0, k].clone()

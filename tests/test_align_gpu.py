@@ -392,3 +392,25 @@ def test_pnp_initialisation_follows_the_reference_recipe(dev):
     assert la < 0.05 and la < 2.0 * lb + 1e-3 and abs(float(a.get_focals()[0]) - f) < 0.05 * f
     assert rot_err < 2e-2 and tr_err < 5e-2
     assert a.init_focals.shape == (n,) and float((a.init_focals - f).abs().max()) < 0.06 * f
+
+
+def test_pnp_initialisation_vs_the_reference_init_from_group(dev):
+    """tests/golden/pnp_init_tiny.pt = the REFERENCE's init_from_group (align_group -> fast_pnp -> init_from_pts3d_group,
+    init_im_poses.py:61-214, 569-635) on a 10-image / 4-window scene with ray maps, with cv2.solvePnPRansac stubbed by the same seeded
+    restatement this engine calls (generate.py pnp_init). Everything around the solver must agree: chaining without overwrite, focal
+    bookkeeping, pairwise poses, scale normalisation, depth maps and camera poses."""
+    from geo4d_amd.align import GroupAligner
+    g = torch.load(os.path.join(G, "pnp_init_tiny.pt"), weights_only=False)
+    Gn, S, H, W, _ = g["pred"].shape
+    a = GroupAligner(g["groups"], g["pred"].to(dev), g["conf"].squeeze(-1).to(dev), shared_focal=True, temporal_smoothing_weight=0.015, translation_weight=1.0)
+    a.init_from_group(None, raymaps=g["rays"].expand(Gn, S, H, W, 3).to(dev), pose_init="pnp", niter_PnP=g["niter_PnP"])
+    ref = g["after_init"]
+    got = {k: a.P[k].detach().cpu() for k in ref}
+    for k in ("im_poses", "pw_poses"):                      # quaternions are defined up to sign
+        sign = torch.sign((got[k][:, :4] * ref[k][:, :4]).sum(1, keepdim=True))
+        got[k] = torch.cat([got[k][:, :4] * sign, got[k][:, 4:]], 1)
+    errs = {k: float((got[k].reshape(ref[k].shape) - ref[k]).abs().max()) for k in ref}
+    loss = float(a.loss_and_grads()[0])
+    print(f"[pnp init vs reference] max abs parameter differences {errs}; loss {loss:.5f} (reference {g['loss']:.5f})")
+    assert errs["im_focals"] < 1e-3 and errs["pw_poses"] < 2e-3 and errs["im_poses"] < 5e-3 and errs["im_depthmaps"] < 5e-3, errs
+    assert abs(loss - g["loss"]) < 0.05 * g["loss"] + 1e-4
