@@ -75,6 +75,23 @@ class Align(C.Structure):
     ]
 
 
+class AlignSmall(C.Structure):
+    _fields_ = [
+        ("im_poses", C.c_void_p), ("im_focals", C.c_void_p), ("pw_poses", C.c_void_p), ("cams", C.c_void_p), ("slot_trf", C.c_void_p),
+        ("img_sums", C.c_void_p), ("slot_sums", C.c_void_p), ("group_ptr", C.c_void_p), ("group_entries", C.c_void_p), ("group_sums", C.c_void_p),
+        ("scale_terms", C.c_void_p),
+        ("grad_im_poses", C.c_void_p), ("grad_im_focals", C.c_void_p), ("grad_pw_poses", C.c_void_p), ("grad_s_depth", C.c_void_p),
+        ("grad_t_depth", C.c_void_p), ("loss", C.c_void_p),
+        ("slot_st", C.c_void_p), ("s_depth", C.c_void_p), ("t_depth", C.c_void_p), ("depth_ok", C.c_void_p),
+        ("traj", C.c_void_p), ("traj_align", C.c_void_p), ("traj_valid", C.c_void_p), ("slot_img", C.c_void_p), ("img_slot_ptr", C.c_void_p),
+        ("img_slot_idx", C.c_void_p), ("grad_traj", C.c_void_p),
+        ("n_imgs", C.c_int), ("n_groups", C.c_int), ("n_slots", C.c_int), ("slots_per_group", C.c_int), ("n_listed_slots", C.c_int),
+        ("n_focals", C.c_int), ("norm_pw_scale", C.c_int),
+        ("focal_break", C.c_float), ("base_scale", C.c_float), ("ppx", C.c_float), ("ppy", C.c_float), ("smooth_weight", C.c_float),
+        ("translation_weight", C.c_float), ("traj_weight", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); checked against include/geo4d_hip.h by tests/test_host_logic.py::test_c_abi_exports_every_declared_symbol
 SIGNATURES = {
     "geo4d_conv_gemm": (C.c_int, [C.POINTER(ConvGemm), C.c_void_p]),
@@ -128,6 +145,8 @@ SIGNATURES = {
     "geo4d_lad_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_float, C.c_float,
                                   C.c_void_p, C.c_void_p]),
     "geo4d_last_error": (C.c_char_p, []),
+    "geo4d_align_refresh": (C.c_int, [C.POINTER(AlignSmall), C.c_void_p]),
+    "geo4d_align_small_grads": (C.c_int, [C.POINTER(AlignSmall), C.c_void_p]),
     "geo4d_abi_version": (C.c_int, []),
     "geo4d_abi_struct_size": (C.c_size_t, [C.c_int]),
 }
@@ -157,7 +176,7 @@ def load():
         fn.argtypes = args
     if lib.geo4d_abi_version() != ABI_VERSION:
         raise Geo4DNativeError(f"ABI mismatch: library {lib.geo4d_abi_version()} vs binding {ABI_VERSION}; rebuild")
-    for which, struct in enumerate((ConvGemm, GroupNorm, Attention, Align)):
+    for which, struct in enumerate((ConvGemm, GroupNorm, Attention, Align, AlignSmall)):
         if lib.geo4d_abi_struct_size(which) != C.sizeof(struct):
             raise Geo4DNativeError(f"ABI mismatch: {struct.__name__} is {lib.geo4d_abi_struct_size(which)} bytes in the library, "
                                    f"{C.sizeof(struct)} in the binding; rebuild")

@@ -46,6 +46,7 @@ import torch
 from . import _lib, ops
 
 FOCAL_BREAK = 20.0
+TORCH_CHAIN = __import__("os").environ.get("GEO4D_ALIGN_CHAIN", "hip") == "torch"   # round 2's autograd chain rule instead of align_small.hip
 
 
 def signed_expm1(x):
@@ -179,6 +180,13 @@ class GroupAligner:
         self.slot_idx = torch.tensor([s for lst in slots for s in lst], dtype=torch.int32, device=self.dev)
         self.slot_order = torch.tensor([s for lst in slots for s in lst], dtype=torch.long, device=self.dev)   # CSR position -> slot
         self.slot_group = torch.tensor([s // S for s in range(G * S)], dtype=torch.long, device=self.dev)
+        all_slots = [[s for s, i in enumerate(e_all) if i == img] for img in range(self.n)]      # every window's slots (not shard-restricted)
+        self._img_slot_ptr = torch.tensor(np.concatenate([[0], np.cumsum([len(x) for x in all_slots])]).astype(np.int32), device=self.dev)
+        self._img_slot_idx = torch.tensor([x for lst in all_slots for x in lst], dtype=torch.int32, device=self.dev)
+        order = [s for lst in slots for s in lst]                  # CSR entry -> slot; per window: its entries, ascending (align_small.hip)
+        by_group = [[e for e, s in enumerate(order) if s // S == g] for g in range(G)]
+        self._group_ptr = torch.tensor(np.concatenate([[0], np.cumsum([len(b) for b in by_group])]).astype(np.int32), device=self.dev)
+        self._group_entries = torch.tensor([e for b in by_group for e in b] or [0], dtype=torch.int32, device=self.dev)
         self.chunk = chunk_pixels
         f0 = FOCAL_BREAK * math.log(max(H, W))
         z = lambda *s: torch.zeros(s, device=self.dev)
@@ -250,8 +258,75 @@ class GroupAligner:
         return (cam @ R.transpose(1, 2) + t[:, None]).reshape(self.n, self.H, self.W, 3)
 
     # ---- one loss / gradient evaluation ---------------------------------------------------------------------------------------
+    def _small(self):
+        """The descriptor of the two small-parameter launches (csrc/align_small.hip) for the CURRENT parameter tensors."""
+        sm = _lib.AlignSmall()
+        P = self.P
+        sm.im_poses, sm.im_focals, sm.pw_poses = P["im_poses"].data_ptr(), P["im_focals"].data_ptr(), P["pw_poses"].data_ptr()
+        sm.cams, sm.slot_trf = self._cams.data_ptr(), self._trf.data_ptr()
+        sm.img_sums, sm.slot_sums, sm.group_sums = self._img_sums.data_ptr(), self._slot_sums.data_ptr(), self._group_sums.data_ptr()
+        sm.group_ptr, sm.group_entries = self._group_ptr.data_ptr(), self._group_entries.data_ptr()
+        sm.scale_terms = self._scale_terms.data_ptr()
+        g = self._small_grads
+        sm.grad_im_poses, sm.grad_im_focals, sm.grad_pw_poses, sm.loss = g["im_poses"].data_ptr(), g["im_focals"].data_ptr(), g["pw_poses"].data_ptr(), self._loss.data_ptr()
+        sm.n_imgs, sm.n_groups, sm.n_slots, sm.slots_per_group, sm.n_listed_slots = self.n, self.G, self.G * self.S, self.S, self.n_local_slots
+        sm.n_focals, sm.norm_pw_scale = P["im_focals"].shape[0], int(self.norm_pw_scale)
+        sm.focal_break, sm.base_scale, sm.ppx, sm.ppy = FOCAL_BREAK, self.base_scale, self.W / 2, self.H / 2
+        sm.smooth_weight, sm.translation_weight = (self.tsw if self.primary else 0.0), self.tw
+        return sm
+
     def loss_and_grads(self):
-        """Returns (loss 0-dim device tensor, dict of gradients shaped like self.P; parameters of terms that are off are absent)."""
+        """Returns (loss 0-dim device tensor, dict of gradients shaped like self.P; parameters of terms that are off are absent).
+        Five launches: parameters -> cams / window transforms / (s, t) per slot (align_refresh), the fused residual kernel + its two
+        fixed-order reductions, gradient sums -> parameter gradients (align_small_grads: the chain rule through quaternions / signed-log
+        translations / log focal / normalised log scales, the temporal-smoothing term and the trajectory term, csrc/align_small.hip). `GEO4D_ALIGN_CHAIN=torch` selects round 2's autograd chain instead."""
+        if TORCH_CHAIN:
+            return self._loss_and_grads_torch()
+        late = self._late_keys()
+        z = lambda *s: torch.zeros(s, device=self.dev)
+        if getattr(self, "_cams", None) is None:
+            self._cams, self._trf, self._loss = z(self.n, 16), z(self.G * self.S, 12), z(1)
+            self._group_sums, self._scale_terms = torch.zeros(self.G, 14, device=self.dev, dtype=torch.float64), torch.zeros(self.G, device=self.dev, dtype=torch.float64)
+            self._small_grads = {"im_poses": z(self.n, 7), "im_focals": torch.zeros_like(self.P["im_focals"]), "pw_poses": z(self.G, 8),
+                                 "s_depth": z(self.G, 1), "t_depth": z(self.G, 1)}
+        sm = self._small()
+        depth_on = "s_depth" in late
+        traj_on = "traj_align_poses" in late
+        if depth_on:
+            if getattr(self, "_slot_st", None) is None:
+                self._slot_st = z(self.G * self.S, 3)
+            sm.grad_s_depth, sm.grad_t_depth = self._small_grads["s_depth"].data_ptr(), self._small_grads["t_depth"].data_ptr()
+            sm.slot_st, sm.s_depth, sm.t_depth, sm.depth_ok = self._slot_st.data_ptr(), self.P["s_depth"].data_ptr(), self.P["t_depth"].data_ptr(), self._depth_ok.data_ptr()
+        if traj_on:
+            if "traj_align_poses" not in self._small_grads:
+                self._small_grads["traj_align_poses"] = z(self.G, 8)
+            if self.primary:                                       # pose-only term: one rank evaluates it
+                sm.traj, sm.traj_align, sm.traj_valid = self._traj_full.data_ptr(), self.P["traj_align_poses"].data_ptr(), self._traj_valid.data_ptr()
+                sm.slot_img, sm.img_slot_ptr, sm.img_slot_idx = self.slot_img.data_ptr(), self._img_slot_ptr.data_ptr(), self._img_slot_idx.data_ptr()
+                sm.grad_traj, sm.traj_weight = self._small_grads["traj_align_poses"].data_ptr(), 0.005
+        _lib.check(self.lib.geo4d_align_refresh(C.byref(sm), ops._stream()), "geo4d_align_refresh")
+        a = _lib.Align()
+        a.pred, a.conf, a.logdepth, a.cams, a.slot_trf = self.pred.data_ptr(), self.conf.data_ptr(), self.P["im_depthmaps"].data_ptr(), self._cams.data_ptr(), self._trf.data_ptr()
+        a.slot_ptr, a.slot_idx = self.slot_ptr.data_ptr(), self.slot_idx.data_ptr()
+        a.grad_logdepth, a.img_sums, a.slot_sums = self._grad_ld.data_ptr(), self._img_sums.data_ptr(), self._slot_sums.data_ptr()
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        a.n_imgs, a.n_slots, a.H, a.W, a.chunk_pixels, a.max_slots_per_image = self.n, self.G * self.S, self.H, self.W, self.chunk, self.max_slots
+        a.conf_clamp, a.inv_area = self.conf_clamp, 1.0 / float(self.G * self.S * self.H * self.W)
+        if depth_on:
+            a.invdepth, a.slot_st, a.depth_weight = self.invdepth.data_ptr(), self._slot_st.data_ptr(), 2.0 * a.inv_area
+        _lib.check(self.lib.geo4d_align_residual(C.byref(a), ops._stream()), "geo4d_align_residual")
+        _lib.check(self.lib.geo4d_align_small_grads(C.byref(sm), ops._stream()), "geo4d_align_small_grads")
+        loss = self._loss[0]
+        grads = {k: self._small_grads[k] for k in ("im_poses", "im_focals", "pw_poses") + (("s_depth", "t_depth") if depth_on else ())
+                 + (("traj_align_poses",) if traj_on else ())}
+        grads["im_depthmaps"] = self._grad_ld
+        if self.shard is not None:
+            loss, grads = self.shard.reduce(loss, grads)        # one all-reduce: loss, small gradients, depth gradients of shared images
+        return loss, grads
+
+    def _loss_and_grads_torch(self):
+        """Round 2's form of loss_and_grads: the chain rule from the gradient sums to the parameters by autograd over tiny tensors
+        (~450 launches per iteration). Kept as the independent cross-check of csrc/align_small.hip (tests) and for A/B."""
         late = self._late_keys()
         small = {k: self.P[k].detach().clone().requires_grad_(True) for k in ("im_poses", "im_focals", "pw_poses") + late}
         saved, self.P = self.P, dict(self.P, **small)
@@ -391,6 +466,10 @@ class GroupAligner:
         if self.traj is not None and len(valid_traj_groups):
             vg = torch.tensor(self.state["valid_traj_groups"], dtype=torch.long, device=self.dev)
             self._traj_vg = vg
+            valid = torch.zeros(self.G, dtype=torch.int32)
+            valid[self.state["valid_traj_groups"]] = 1
+            self._traj_valid = valid.to(self.dev)
+            self._traj_full = self.traj.reshape(self.G * self.S, 16).float().contiguous()
             self._traj_idx = self.e_all.reshape(self.G, self.S).index_select(0, vg).reshape(-1)
             self._traj_R, self._traj_t = self.traj.index_select(0, vg)[:, :, :3, :3].contiguous(), self.traj.index_select(0, vg)[:, :, :3, 3].contiguous()
 
@@ -430,10 +509,9 @@ class GroupAligner:
             for k in ("im_poses", "im_focals", "pw_poses") + late:   # a few dozen numbers each: plain tensor ops, same formula
                 if k in self.frozen:
                     continue
-                g, (m, v), h = grads[k], mom[k], hyper_late if k in late else hyper
-                m.mul_(b1).add_(g, alpha=1 - b1)
-                v.mul_(b2).addcmul_(g, g, value=1 - b2)
-                self.P[k].sub_((h[0] / h[1]) * m / (v.sqrt() / h[2] + eps))
+                g, (m, v), h = grads[k].contiguous(), mom[k], hyper_late if k in late else hyper
+                _lib.check(self.lib.geo4d_adam_step_dev(self.P[k].data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self.P[k].numel(),
+                                                        h.data_ptr(), b1, b2, eps, ops._stream()), "geo4d_adam_step_dev")
             idx.add_(1)
 
         def run(count):

@@ -12,6 +12,7 @@
 // in a fixed order (deterministic: no atomics). The chain rule from those 3x3 / 3-vector sums to quaternion, log-translation,
 // log-focal and log-scale parameters is a few hundred flops per image and stays on the host side (geo4d_amd/align.py), as does
 // the camera temporal-smoothing term. Everything here is HBM-bound: 20 B read + 4 B written per slot-pixel.
+#include <cstdlib>
 #include "common.h"
 #include "geo4d_hip.h"
 
@@ -123,6 +124,113 @@ __global__ __launch_bounds__(256) void align_residual_kernel(const geo4d_align_t
         block_sum<SLOT_SUMS>(sslot[j], red, tid);
         if (tid < SLOT_SUMS) p.slot_part[((long)(s0 + j) * gridDim.x + chunk) * SLOT_SUMS + tid] = sslot[j][0];
     }
+}
+
+// ---- round 3: the same arithmetic with the SLOT loop outside and the pixel loop inside ----------------------------------------------
+// align_residual_kernel keeps 14 image sums + 6 x 14 slot sums live across its pixel loop (188 VGPRs, 2 waves per SIMD: 1.34 TB/s on
+// the 128-frame clip, profiles/r02_align_bench.md). Every sum is LINEAR in the per-slot residual gradient a_j, so the slots can be
+// walked one after the other: a thread owns NPX = chunk_pixels / 256 fixed pixels, keeps only their scalar dL/dlogdepth in registers
+// (NPX values) + the 14 image sums + the CURRENT slot's 14 sums, re-derives the camera-frame point of a pixel per slot pass (one
+// v_exp + ~12 flops; the log-depth re-read hits L1 / L2) and reduces the slot sums at the end of each pass. ~90 VGPRs instead of 188.
+// Same partial-sum layout, same fixed-order reductions (deterministic); sums are accumulated slot-major instead of pixel-major, so the
+// results differ from the first kernel by fp32 re-association only.
+template <bool DEPTH, int NPX>
+__global__ __launch_bounds__(256) void align_residual_kernel2(const geo4d_align_t p) {
+    __shared__ float red[4 * SLOT_SUMS > 4 * IMG_SUMS ? 4 * SLOT_SUMS : 4 * IMG_SUMS];
+    const int tid = threadIdx.x, chunk = blockIdx.x, img = blockIdx.y;
+    const int HW = p.H * p.W;
+    const float* cam = p.cams + img * 16;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = cam[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = cam[9 + i];
+    const float f = cam[12], inv_f = 1.0f / f, ppx = cam[13], ppy = cam[14];
+    const int s0 = p.slot_ptr[img], ns = p.slot_ptr[img + 1] - s0;
+    const int px0 = chunk * p.chunk_pixels + tid;
+    float simg[IMG_SUMS], gl[NPX];
+#pragma unroll
+    for (int i = 0; i < IMG_SUMS; ++i) simg[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) gl[k] = 0.f;
+    const float* ld = p.logdepth + (long)img * HW;
+    for (int j = 0; j < ns; ++j) {                                   // uniform over the block
+        const int slot = p.slot_idx[s0 + j];
+        const float* T = p.slot_trf + slot * 12;
+        float Tm[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Tm[i] = T[i];
+        float st0 = 0.f, st1 = 0.f, st2 = 0.f;
+        if constexpr (DEPTH) { st0 = p.slot_st[slot * 3]; st1 = p.slot_st[slot * 3 + 1]; st2 = p.slot_st[slot * 3 + 2]; }
+        const float* pr = p.pred + (long)slot * HW * 3;
+        const float* cf = p.conf + (long)slot * HW;
+        // launder the log-depth pointer once per slot pass: otherwise the loop-invariant code motion hoists d, the camera-frame point
+        // and X of all NPX pixels out of the slot loop and keeps them live (8 registers per pixel: 225 VGPRs at NPX = 16)
+        const float* ldj = ld;
+        int px0j = px0;                              // ... and the pixel index, or every pixel's (u, v) and load addresses stay live too
+        asm volatile("" : "+s"(ldj), "+v"(px0j));
+        float ss[SLOT_SUMS];
+#pragma unroll
+        for (int i = 0; i < SLOT_SUMS; ++i) ss[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            // at most 4 pixels' loads in flight per thread: without the fence hipcc hoists all NPX iterations' loads (240 VGPRs,
+            // 2 waves per SIMD again); with it ~130 VGPRs and 4 waves per SIMD hide the latency instead
+            if (k % 4 == 0 && k > 0) asm volatile("" ::: "memory");
+            const int px = px0j + k * 256;
+            if (px >= HW) continue;
+            const float d = __expf(ldj[px]);
+            const int v = px / p.W, u = px - v * p.W;
+            const float xc = d * ((float)u - ppx) * inv_f, yc = d * ((float)v - ppy) * inv_f, zc = d;
+            const float X0 = R[0] * xc + R[1] * yc + R[2] * zc + t[0];
+            const float X1 = R[3] * xc + R[4] * yc + R[5] * zc + t[1];
+            const float X2 = R[6] * xc + R[7] * yc + R[8] * zc + t[2];
+            float gd = 0.f;
+            if constexpr (DEPTH) {
+                const float invd = 1.0f / (d + 1e-6f);
+                const float q = p.invdepth[(long)slot * HW + px];
+                const float wd = (q > 0.05f ? p.depth_weight : 0.f) * st2;
+                const float rd = invd - (st0 * q + st1);
+                const float sg = rd > 0.f ? wd : (rd < 0.f ? -wd : 0.f);
+                simg[13] += wd * fabsf(rd);
+                gd = sg * d * invd * invd;
+                ss[12] -= sg * q;
+                ss[13] -= sg;
+            }
+            const float3 Pv = *(const float3*)(pr + (long)px * 3);
+            const float P0 = Pv.x, P1 = Pv.y, P2 = Pv.z;
+            const float r0 = X0 - (Tm[0] * P0 + Tm[1] * P1 + Tm[2] * P2 + Tm[9]);
+            const float r1 = X1 - (Tm[3] * P0 + Tm[4] * P1 + Tm[5] * P2 + Tm[10]);
+            const float r2 = X2 - (Tm[6] * P0 + Tm[7] * P1 + Tm[8] * P2 + Tm[11]);
+            const float nr = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+            const float w = fminf(cf[px], p.conf_clamp) * p.inv_area;
+            simg[13] += w * nr;
+            const float kk = nr > 0.f ? w / nr : 0.f;
+            const float a0 = kk * r0, a1 = kk * r1, a2 = kk * r2;
+            ss[0] -= a0 * P0; ss[1] -= a0 * P1; ss[2] -= a0 * P2;
+            ss[3] -= a1 * P0; ss[4] -= a1 * P1; ss[5] -= a1 * P2;
+            ss[6] -= a2 * P0; ss[7] -= a2 * P1; ss[8] -= a2 * P2;
+            ss[9] -= a0; ss[10] -= a1; ss[11] -= a2;
+            const float c0 = R[0] * a0 + R[3] * a1 + R[6] * a2;
+            const float c1 = R[1] * a0 + R[4] * a1 + R[7] * a2;
+            const float c2 = R[2] * a0 + R[5] * a1 + R[8] * a2;
+            gl[k] += c0 * xc + c1 * yc + c2 * zc - gd;
+            simg[0] += a0 * xc; simg[1] += a0 * yc; simg[2] += a0 * zc;
+            simg[3] += a1 * xc; simg[4] += a1 * yc; simg[5] += a1 * zc;
+            simg[6] += a2 * xc; simg[7] += a2 * yc; simg[8] += a2 * zc;
+            simg[9] += a0; simg[10] += a1; simg[11] += a2;
+            simg[12] -= (c0 * xc + c1 * yc) * inv_f;
+        }
+        block_sum<SLOT_SUMS>(ss, red, tid);
+        if (tid < SLOT_SUMS) p.slot_part[((long)(s0 + j) * gridDim.x + chunk) * SLOT_SUMS + tid] = ss[0];
+    }
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const int px = px0 + k * 256;
+        if (px < HW) p.grad_logdepth[(long)img * HW + px] = gl[k];
+    }
+    block_sum<IMG_SUMS>(simg, red, tid);
+    if (tid < IMG_SUMS) p.img_part[((long)img * gridDim.x + chunk) * IMG_SUMS + tid] = simg[0];
 }
 
 // out[row][c] = sum over chunks (fixed order) of part[row][chunk][c]; one thread per (row, c)
@@ -349,8 +457,20 @@ extern "C" int geo4d_align_residual(const geo4d_align_t* pp, void* stream) {
     p.img_part = (float*)p.workspace;
     p.slot_part = p.img_part + (size_t)p.n_imgs * nchunk * IMG_SUMS;
     hipStream_t s = (hipStream_t)stream;
-    if (p.invdepth) hipLaunchKernelGGL(align_residual_kernel<true>, dim3(nchunk, p.n_imgs), dim3(256), 0, s, p);
+    // slot-major kernel (round 3) for the chunk sizes it is instantiated for; the pixel-major kernel serves any other multiple of 256
+#define GEO4D_ALIGN2(NPX_)                                                                                                        \
+    do {                                                                                                                           \
+        if (p.invdepth) hipLaunchKernelGGL((align_residual_kernel2<true, NPX_>), dim3(nchunk, p.n_imgs), dim3(256), 0, s, p);       \
+        else hipLaunchKernelGGL((align_residual_kernel2<false, NPX_>), dim3(nchunk, p.n_imgs), dim3(256), 0, s, p);                  \
+    } while (0)
+    const bool v1 = getenv("GEO4D_ALIGN_KERNEL") && atoi(getenv("GEO4D_ALIGN_KERNEL")) == 1;
+    if (!v1 && p.chunk_pixels == 4096) GEO4D_ALIGN2(16);
+    else if (!v1 && p.chunk_pixels == 2048) GEO4D_ALIGN2(8);
+    else if (!v1 && p.chunk_pixels == 1024) GEO4D_ALIGN2(4);
+    else if (!v1 && p.chunk_pixels == 256) GEO4D_ALIGN2(1);
+    else if (p.invdepth) hipLaunchKernelGGL(align_residual_kernel<true>, dim3(nchunk, p.n_imgs), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(align_residual_kernel<false>, dim3(nchunk, p.n_imgs), dim3(256), 0, s, p);
+#undef GEO4D_ALIGN2
     GEO4D_CHECK_LAUNCH();
     hipLaunchKernelGGL(align_reduce_kernel, dim3((p.n_imgs * IMG_SUMS + 255) / 256), dim3(256), 0, s, p.img_part, p.img_sums, p.n_imgs, nchunk, IMG_SUMS);
     GEO4D_CHECK_LAUNCH();

@@ -313,6 +313,7 @@ extern "C" size_t geo4d_abi_struct_size(int which) {
         case 1: return sizeof(geo4d_groupnorm_t);
         case 2: return sizeof(geo4d_attention_t);
         case 3: return sizeof(geo4d_align_t);
+        case 4: return sizeof(geo4d_align_small_t);
         default: return 0;
     }
 }

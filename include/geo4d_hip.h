@@ -236,6 +236,37 @@ int geo4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int geo4d_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const float* hyper, float beta1,
                         float beta2, float eps, void* stream);
 
+/* The parameter side of one alignment iteration (round 3; base_opt_group.py:262-327 parameterisation, optimizer_group.py:529-541
+ * relative_pose_loss): geo4d_align_refresh writes the residual kernel's inputs from the parameters - cams [n_imgs][16] =
+ * (R row-major | t | f | ppx | ppy | 0) with R = rotation of the NORMALISED XYZW quaternion im_poses[i][0:4], t = signed_expm1 of
+ * im_poses[i][4:7], f = exp(im_focals / focal_break); slot_trf [n_slots][12] = (s_g R_g | s_g t_g) of the slot's window g = slot /
+ * slots_per_group with s_g = exp(pw_poses[g][7] + (norm_pw_scale ? log base_scale - mean_g pw_poses[g][7] : 0)).
+ * geo4d_align_small_grads turns the residual kernel's gradient sums (img_sums [n_imgs][14]; slot_sums [n_listed_slots][14] in the CSR
+ * order of slot_idx, listed per window by group_ptr / group_entries) into loss[0] = sum_i img_sums[i][13] + smooth_weight * sum_i
+ * relative_pose_loss(cam_i, cam_i+1) and the gradients of im_poses [n_imgs][7], im_focals [n_focals] (1 = shared), pw_poses
+ * [n_groups][8] and, when given, s_depth / t_depth [n_groups]. One workgroup, fixed-order sums, fp64 inside (several of the sums cancel).
+ * replaces loss.backward() through the tiny parameter tensors (round 2: ~450 autograd launches per iteration). */
+typedef struct geo4d_align_small_t {
+    const float* im_poses; const float* im_focals; const float* pw_poses;
+    float* cams; float* slot_trf;
+    const float* img_sums; const float* slot_sums;
+    const int* group_ptr; const int* group_entries;   /* window g owns CSR entries group_entries[group_ptr[g] .. group_ptr[g + 1]) (ascending) */
+    double* group_sums; double* scale_terms;   /* scratch: [n_groups][14] and [n_groups] fp64 */
+    float* grad_im_poses; float* grad_im_focals; float* grad_pw_poses; float* grad_s_depth; float* grad_t_depth; float* loss;
+    /* inverse-depth term (all NULL: off): geo4d_align_refresh also writes slot_st [n_slots][3] = (s_depth[g], t_depth[g], depth_ok[g]) */
+    float* slot_st; const float* s_depth; const float* t_depth; const float* depth_ok;
+    /* trajectory term (traj NULL: off; optimizer_group.py:496-512): traj [n_slots][4][4] = every window's predicted camera-to-world
+     * matrices, traj_align [n_groups][8] = traj_align_poses, traj_valid [n_groups] (0 / 1), slot_img [n_slots] = image of a slot,
+     * img_slot_ptr / img_slot_idx = CSR of ALL slots per image; loss += traj_weight * sum relative_pose_loss(T_g [R_k | e^l t_k], cam_i);
+     * grad_traj [n_groups][8] receives d/d traj_align_poses (zero rows for invalid windows); the camera side is added to grad_im_poses */
+    const float* traj; const float* traj_align; const int* traj_valid; const int* slot_img; const int* img_slot_ptr; const int* img_slot_idx;
+    float* grad_traj;
+    int n_imgs, n_groups, n_slots, slots_per_group, n_listed_slots, n_focals, norm_pw_scale;
+    float focal_break, base_scale, ppx, ppy, smooth_weight, translation_weight, traj_weight;
+} geo4d_align_small_t;
+int geo4d_align_refresh(const geo4d_align_small_t* p, void* stream);
+int geo4d_align_small_grads(const geo4d_align_small_t* p, void* stream);
+
 /* Start-up of the inverse-depth term (LightPointCloudGroupOptimizer._set_st_depth, optimizer_group.py:333-372, which calls
  * dust3r/depth_eval.py depth_evaluation(align_with_lad2=True) :147-330 per window). All arrays fp32 on the device, windows
  * contiguous: q / target / conf are [G][n], n = S * H * W.
@@ -256,7 +287,7 @@ int geo4d_lad_delta(const float* q, const float* target, const float* conf, cons
 
 const char* geo4d_last_error(void);
 int geo4d_abi_version(void);
-/* sizeof of the parameter structs as the LIBRARY was compiled (which: 0 conv_gemm, 1 groupnorm, 2 attention, 3 align; else 0):
+/* sizeof of the parameter structs as the LIBRARY was compiled (which: 0 conv_gemm, 1 groupnorm, 2 attention, 3 align, 4 align_small; else 0):
  * bindings compare it with their own layout at load time. */
 size_t geo4d_abi_struct_size(int which);
 
