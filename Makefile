@@ -10,7 +10,7 @@ CXXFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Igeo4d_amd/cs
 
 all: $(LIB)
 
-build/%.o: geo4d_amd/csrc/%.hip geo4d_amd/csrc/common.h geo4d_amd/csrc/gemm_kernel.h geo4d_amd/csrc/gemm_kernel_v2.h include/geo4d_hip.h
+build/%.o: geo4d_amd/csrc/%.hip geo4d_amd/csrc/common.h geo4d_amd/csrc/gemm_kernel.h geo4d_amd/csrc/gemm_kernel_v2.h geo4d_amd/csrc/gemm_kernel_v3.h include/geo4d_hip.h
 	@mkdir -p build
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 

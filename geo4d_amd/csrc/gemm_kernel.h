@@ -594,6 +594,8 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 // tile hints 21..39 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups) are instantiated in their own
 // translation units (gemm_v2_*.hip) so that the two kernel generations compile in parallel
 template <typename T> int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream);
+// tile hints 71..74 (gemm_kernel_v3.h: the same with a phased, counted-wait K loop on staggered wave groups): gemm_v3_*.hip
+template <typename T> int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream);
 
 // Tile choice: score = MFMA efficiency of the tile shape x useful fraction x how full the last wave of
 // workgroups is (2 workgroups fit per CU by LDS => 512 slots on 256 CUs). Split-K multiplies the workgroup count
@@ -603,6 +605,7 @@ struct TileCfg { int bm, bn; float eff; };
 template <typename T>
 int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     static constexpr TileCfg cfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.80f}, {64, 64, 0.62f}, {128, 32, 0.50f}};
+    if (p.tile_hint >= 71) return launch_v3_typed<T>(p, stream);
     if (p.tile_hint >= 21) return launch_v2_typed<T>(p, stream);
     if (p.o_split) {     // the pre-split output format lives in the register epilogue of the second-generation kernel only
         geo4d_conv_gemm_t q = p;

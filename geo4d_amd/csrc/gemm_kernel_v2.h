@@ -42,6 +42,116 @@ template <typename T> __device__ __forceinline__ int swz_key(int row) {
     else return p;
 }
 
+// ---- register epilogue shared by the second- and third-generation kernels: acc[a][b][j] is out[m_w0 + 16a + lr][n_w0 + 16b + 4lq + j]
+// (bias / row-bias / activation / GEGLU / residual / rounding in registers, 16-byte (f32) or 8-byte (16-bit) stores). `partial`:
+// split-K launch, the raw fp32 slab of split e_kz goes to the workspace and the epilogue runs in splitk_reduce_kernel.
+template <int MB, int NB, bool OSPLIT, bool VECONLY = false>   // VECONLY: the host checked the vector-store conditions (no scalar fallback code)
+__device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f32x4 (&acc)[MB][NB], const int m_w0, const int n_w0,
+                                             const long e_bz, const int e_kz, const bool partial, const int lr, const int lq) {
+    const int odt = partial ? GEO4D_F32 : p.out_dtype;
+    const int oesz = odt == GEO4D_F32 ? 4 : 2;
+    const bool geglu = !partial && p.act == 2;
+    const int nout = geglu ? (p.N >> 1) : p.N;
+    void* O = partial ? (void*)((float*)p.workspace + ((long)e_kz * p.batch + e_bz) * (long)p.M * p.N) : p.O;
+    const long ldo = partial ? (long)p.N : p.ldo;
+    const long obase = partial ? 0 : e_bz * p.o_bs;
+    const bool has_res = !partial && p.R != nullptr;
+    const long rbase = e_bz * p.r_bs;
+    // 4-element vectors need 4-element aligned rows and bases (16 B for f32, 8 B for 16-bit outputs)
+    const bool vec_ok = VECONLY || ((nout & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)O + obase * oesz) % (4 * oesz)) == 0 &&
+                                    (!has_res || ((p.ldr & 3) == 0 && (((uintptr_t)p.R + rbase * oesz) % (4 * oesz)) == 0)));
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+        const int m = m_w0 + a * 16 + lr;
+        if (m >= p.M) continue;
+        const float brow = (!partial && p.bias && p.bias_per_row) ? p.bias[m] : 0.f;
+        const long rboff = (!partial && p.rowbias) ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
+        if (geglu) {
+            if constexpr (NB % 4 == 0) {
+                // packed GEGLU weights interleave value / gate in 32-column blocks: 16-blocks 4j, 4j+1 = value, 4j+2, 4j+3 = gate
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if ((b & 3) >= 2) continue;
+                    const int n = n_w0 + 16 * b + 4 * lq;                       // value column; its gate sits 32 columns further
+                    if (n + 32 >= p.N) continue;
+                    const int oc = (n_w0 >> 1) + 32 * (b >> 2) + 16 * (b & 1) + 4 * lq;
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xv = acc[a][b][j] * p.alpha + (p.bias ? p.bias[n + j] : 0.f);
+                        const float gv = acc[a][b + 2 < NB ? b + 2 : b][j] * p.alpha + (p.bias ? p.bias[n + 32 + j] : 0.f);
+                        e[j] = xv * gelu_erf_f(gv);
+                    }
+                    const long oidx = obase + (long)m * ldo + oc;
+                    if (vec_ok) {
+                        if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
+                        else if (odt == GEO4D_F32) *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
+                        else if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
+                        else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) store_out(O, oidx + j, e[j], odt);
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int n = n_w0 + 16 * b + 4 * lq;
+            if (n >= p.N) continue;
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = acc[a][b][j];
+            const long oidx = obase + (long)m * ldo + n;
+            if (!partial) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = e[j] * p.alpha + brow;
+                    if (n + j < p.N) {
+                        if (p.bias && !p.bias_per_row) v += p.bias[n + j];
+                        if (p.rowbias) v += p.rowbias[rboff + n + j];
+                    }
+                    if (p.act == 1) v = silu_f(v);
+                    else if (p.act == 3) v = gelu_erf_f(v);
+                    e[j] = v;
+                }
+            }
+            if (vec_ok) {
+                if (odt == GEO4D_F32) {
+                    if (has_res) {
+                        const f32x4 r = *(const f32x4*)((const float*)p.R + rbase + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e[j] += r[j];
+                    }
+                    *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
+                } else {
+                    if (has_res) {
+                        const u32x2 r = *(const u32x2*)((const unsigned short*)p.R + rbase + (long)m * p.ldr + n);
+                        if (odt == GEO4D_BF16) {
+                            e[0] += __uint_as_float(r[0] << 16); e[1] += __uint_as_float(r[0] & 0xffff0000u);
+                            e[2] += __uint_as_float(r[1] << 16); e[3] += __uint_as_float(r[1] & 0xffff0000u);
+                        } else {
+                            e[0] += f16_bits_to_f32((unsigned short)(r[0] & 0xffffu)); e[1] += f16_bits_to_f32((unsigned short)(r[0] >> 16));
+                            e[2] += f16_bits_to_f32((unsigned short)(r[1] & 0xffffu)); e[3] += f16_bits_to_f32((unsigned short)(r[1] >> 16));
+                        }
+                    }
+                    if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
+                    else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= p.N) continue;
+                    float v = e[j];
+                    if (has_res) v += load_res(p.R, rbase + (long)m * p.ldr + n + j, odt);
+                    store_out(O, oidx + j, v, odt);
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int NA>
 constexpr int v2_smem_bytes() { return (NA * BM + 2 * BN) * PITCH + BM * MAXTAP * 4; }
 
@@ -250,112 +360,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         }
     };
 
-    // ---- epilogue: acc[a][b][j] is out[m_w0 + 16a + lr][n_w0 + 16b + 4lq + j] -------------------------------------------------------
     const bool partial = splits > 1;                  // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
-    const int odt = partial ? GEO4D_F32 : p.out_dtype;
-    const int oesz = odt == GEO4D_F32 ? 4 : 2;
-    const bool geglu = !partial && p.act == 2;
-    const int nout = geglu ? (p.N >> 1) : p.N;
     auto epilogue = [&](int e_tm, int e_tn, long e_bz, int e_kz) {
-        const int m_w0 = e_tm * BM + wr * WTM, n_w0 = e_tn * BN + wc * WTN;
-        void* O = partial ? (void*)((float*)p.workspace + ((long)e_kz * p.batch + e_bz) * (long)p.M * p.N) : p.O;
-        const long ldo = partial ? (long)p.N : p.ldo;
-        const long obase = partial ? 0 : e_bz * p.o_bs;
-        const bool has_res = !partial && p.R != nullptr;
-        const long rbase = e_bz * p.r_bs;
-        // 4-element vectors need 4-element aligned rows and bases (16 B for f32, 8 B for 16-bit outputs)
-        const bool vec_ok = (nout & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)O + obase * oesz) % (4 * oesz)) == 0 &&
-                            (!has_res || ((p.ldr & 3) == 0 && (((uintptr_t)p.R + rbase * oesz) % (4 * oesz)) == 0));
-#pragma unroll
-        for (int a = 0; a < MB; ++a) {
-            const int m = m_w0 + a * 16 + lr;
-            if (m >= p.M) continue;
-            const float brow = (!partial && p.bias && p.bias_per_row) ? p.bias[m] : 0.f;
-            const long rboff = (!partial && p.rowbias) ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
-            if (geglu) {
-                if constexpr (NB % 4 == 0) {
-                    // packed GEGLU weights interleave value / gate in 32-column blocks: 16-blocks 4j, 4j+1 = value, 4j+2, 4j+3 = gate
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        if ((b & 3) >= 2) continue;
-                        const int n = n_w0 + 16 * b + 4 * lq;                       // value column; its gate sits 32 columns further
-                        if (n + 32 >= p.N) continue;
-                        const int oc = (n_w0 >> 1) + 32 * (b >> 2) + 16 * (b & 1) + 4 * lq;
-                        float e[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float xv = acc[a][b][j] * p.alpha + (p.bias ? p.bias[n + j] : 0.f);
-                            const float gv = acc[a][b + 2 < NB ? b + 2 : b][j] * p.alpha + (p.bias ? p.bias[n + 32 + j] : 0.f);
-                            e[j] = xv * gelu_erf_f(gv);
-                        }
-                        const long oidx = obase + (long)m * ldo + oc;
-                        if (vec_ok) {
-                            if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
-                            else if (odt == GEO4D_F32) *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
-                            else if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
-                            else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) store_out(O, oidx + j, e[j], odt);
-                        }
-                    }
-                }
-                continue;
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int n = n_w0 + 16 * b + 4 * lq;
-                if (n >= p.N) continue;
-                float e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = acc[a][b][j];
-                const long oidx = obase + (long)m * ldo + n;
-                if (!partial) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = e[j] * p.alpha + brow;
-                        if (n + j < p.N) {
-                            if (p.bias && !p.bias_per_row) v += p.bias[n + j];
-                            if (p.rowbias) v += p.rowbias[rboff + n + j];
-                        }
-                        if (p.act == 1) v = silu_f(v);
-                        else if (p.act == 3) v = gelu_erf_f(v);
-                        e[j] = v;
-                    }
-                }
-                if (vec_ok) {
-                    if (odt == GEO4D_F32) {
-                        if (has_res) {
-                            const f32x4 r = *(const f32x4*)((const float*)p.R + rbase + (long)m * p.ldr + n);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) e[j] += r[j];
-                        }
-                        *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
-                    } else {
-                        if (has_res) {
-                            const u32x2 r = *(const u32x2*)((const unsigned short*)p.R + rbase + (long)m * p.ldr + n);
-                            if (odt == GEO4D_BF16) {
-                                e[0] += __uint_as_float(r[0] << 16); e[1] += __uint_as_float(r[0] & 0xffff0000u);
-                                e[2] += __uint_as_float(r[1] << 16); e[3] += __uint_as_float(r[1] & 0xffff0000u);
-                            } else {
-                                e[0] += f16_bits_to_f32((unsigned short)(r[0] & 0xffffu)); e[1] += f16_bits_to_f32((unsigned short)(r[0] >> 16));
-                                e[2] += f16_bits_to_f32((unsigned short)(r[1] & 0xffffu)); e[3] += f16_bits_to_f32((unsigned short)(r[1] >> 16));
-                            }
-                        }
-                        if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
-                        else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (n + j >= p.N) continue;
-                        float v = e[j];
-                        if (has_res) v += load_res(p.R, rbase + (long)m * p.ldr + n + j, odt);
-                        store_out(O, oidx + j, v, odt);
-                    }
-                }
-            }
-        }
+        reg_epilogue<MB, NB, OSPLIT>(p, acc, e_tm * BM + wr * WTM, e_tn * BN + wc * WTN, e_bz, e_kz, partial, lr, lq);
     };
 
     // ---- persistent tile loop --------------------------------------------------------------------------------------------------------

@@ -1,0 +1,7 @@
+// geo4d_amd/csrc/gemm_v3_f32.hip — third-generation conv_gemm kernels (tile hints 71..74, phased K loop) for element type float
+// (one translation unit per type: parallel build).
+#include "gemm_kernel_v3.h"
+
+namespace geo4d_gemm {
+template int launch_v3_typed<float>(const geo4d_conv_gemm_t&, hipStream_t);
+}  // namespace geo4d_gemm

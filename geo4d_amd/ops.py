@@ -96,7 +96,11 @@ _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1
                # round 3 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups; refused for f32 / NCTHW outputs)
                (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (21, 2), (21, 4), (21, 8), (22, 2), (22, 4),
                (23, 2), (24, 2), (24, 4), (25, 2), (25, 4), (25, 8), (26, 2), (26, 4), (27, 2), (27, 4), (28, 2), (28, 4), (28, 8), (29, 2),
-               (31, 1), (33, 1), (34, 1), (35, 1), (39, 1), (31, 2), (31, 4), (31, 8), (33, 2), (33, 4), (34, 2), (34, 4), (35, 2), (35, 4), (35, 8)]
+               (31, 1), (33, 1), (34, 1), (35, 1), (39, 1), (31, 2), (31, 4), (31, 8), (33, 2), (33, 4), (34, 2), (34, 4), (35, 2), (35, 4), (35, 8),
+               # round 3 (gemm_kernel_v3.h: phased K loop, counted DMA waits, staggered wave groups; 8-wave tiles, one workgroup per CU).
+               # Splits that do not divide the K slabs evenly run on the second-generation twin inside the library.
+               (71, 1), (72, 1), (73, 1), (74, 1), (71, 2), (72, 2), (73, 2), (74, 2), (71, 3), (72, 3), (73, 3), (74, 3), (71, 4), (73, 4), (74, 4),
+               (71, 5), (73, 5), (74, 5), (73, 6), (74, 6), (73, 8), (74, 8), (73, 10), (74, 10)]
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
 # GEMM epilogues can emit the next GroupNorm's column sums (gn_stats=True call sites). OFF by default: measured on MI355X the fused
 # path is correct but not faster yet (round 2: -3.5 % bf16x3, -7 % bf16 with the first finalize kernel) - the epilogue work lands on

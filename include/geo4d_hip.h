@@ -65,8 +65,13 @@ typedef struct geo4d_conv_gemm_t {
                             80x80 wave tiles), 24 = 160x160 (4 waves), 25 = 128x128, 26 = 128x64, 27 = 64x128, 28 = 64x64,
                             29 = 128x256; the same with THREE activation-panel
                             buffers (the A panel two K slabs ahead): 31 = 256x128, 33 = 160x320, 34 = 160x160, 35 = 128x128,
-                            39 = 128x256; GEGLU on 21, 22, 25, 27, 29, 31, 35, 39. Others: -EINVAL */
-    int split_k;         /* 0 auto, 1 never, 2/4/8/16 force (needs workspace)           */
+                            39 = 128x256; GEGLU on 21, 22, 25, 27, 29, 31, 35, 39. The same MFMA form and epilogue under a PHASED
+                            K loop (4 phases per slab, counted LDS-DMA waits, two staggered wave groups, the staging cursor
+                            two slabs ahead across tiles; 8 waves, one workgroup per CU): 71 = 256x256, 72 = 160x320,
+                            73 = 256x128, 74 = 128x256; GEGLU on 71, 74; launches with fewer than 2 slabs per tile, an uneven
+                            split-K or outputs that are not 4-element aligned run on 22 / 23 / 21 / 29 instead.
+                            Others: -EINVAL */
+    int split_k;         /* 0 auto (powers of two), 1 never, n >= 2: n-way split (needs workspace; tile hints >= 21 take any n) */
     int debug_ablate;    /* 0 in production. 1 (bf16x3 profiling only): skip the in-register hi/lo split -> WRONG results;
                             2 (tests only, tile hints >= 21): launch 3 persistent workgroups whatever the problem size */
     float alpha;

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
     ap.add_argument("--explore2", action="store_true", help="per shape: best 32x32-MFMA configuration (tile hints 1..17) vs best second-generation one (21..29), and every 21..29 tile at split 1")
     ap.add_argument("--tiles", default="", help="comma list of tile hints to time per shape (split 1), e.g. the ablation builds 40..64")
+    ap.add_argument("--presplit", action="store_true", help="bf16x3: hand the activation over in the producers' pre-split format (what the networks run)")
     ap.add_argument("--ablate", type=int, default=0, help="bf16x3 only: 1 = skip the in-register operand split (wrong numbers; measures its cost)")
     args = ap.parse_args()
     ops.DEBUG_ABLATE = args.ablate
@@ -66,6 +67,7 @@ def main():
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "bf16x3": torch.float32}[args.dtype]
     from geo4d_amd import pack
     wcast = (lambda w: pack.split_bf16(w)) if x3 else (lambda w: w.to(dt))
+    acast = (lambda a: ops.SplitAct.wrap(pack.split_bf16(a))) if (x3 and args.presplit) else (lambda a: a)
     dev = torch.device("cuda:0")
     tot_ms, tot_tf = 0.0, 0.0
     print(f"{'shape':34s} {'M':>8s} {'N':>6s} {'K':>6s} {'us':>9s} {'TF/s':>8s}  x count -> ms/forward")
@@ -79,21 +81,24 @@ def main():
             w = wcast(torch.randn((N, K), device=dev) / K ** 0.5)
             b = torch.randn((N,), device=dev)
             r = torch.randn((M, N), device=dev).to(dt)
-            fn = lambda tile=args.tile, split=args.split: ops.conv2d(x, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=r, tile_hint=tile, split_k=split)
+            xa = acast(x)
+            fn = lambda tile=args.tile, split=args.split: ops.conv2d(xa, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=r, tile_hint=tile, split_k=split)
         elif kind == "t3":
             T, HW = geo
             M, K = T * HW, 3 * Cin
             x = torch.randn((M, Cin), device=dev).to(dt)
             w = wcast(torch.randn((N, K), device=dev) / K ** 0.5)
             b = torch.randn((N,), device=dev)
-            fn = lambda tile=args.tile, split=args.split: ops.conv_gemm(x, w, torch.empty((M, N), device=dev, dtype=dt), M=M, N=N, K=K, Cin=Cin, lda=Cin, ldw=w.stride(0), ldo=N, T=T, Hin=HW, Win=1, Hout=HW, Wout=1, KT=3, pt=1, bias=b, residual=x, ldr=Cin, tile_hint=tile, split_k=split)
+            xa = acast(x)
+            fn = lambda tile=args.tile, split=args.split: ops.conv_gemm(xa, w, torch.empty((M, N), device=dev, dtype=dt), M=M, N=N, K=K, Cin=Cin, lda=Cin, ldw=w.stride(0), ldo=N, T=T, Hin=HW, Win=1, Hout=HW, Wout=1, KT=3, pt=1, bias=b, residual=x, ldr=Cin, tile_hint=tile, split_k=split)
         else:
             M, K = geo, Cin
             x = torch.randn((M, K), device=dev).to(dt)
             w = wcast(torch.randn((N, K), device=dev) / K ** 0.5)
             b = torch.randn((N,), device=dev)
             act = 2 if kind == "geglu" else 0
-            fn = lambda tile=args.tile, split=args.split: ops.linear(x, w, b, act=act, tile_hint=tile, split_k=split)
+            xa = acast(x)
+            fn = lambda tile=args.tile, split=args.split: ops.linear(xa, w, b, act=act, tile_hint=tile, split_k=split)
         def timeit(**kw):
             for _ in range(2):
                 fn(**kw)
@@ -140,8 +145,9 @@ def main():
         if args.tiles:
             row = []
             for t in args.tiles.split(","):
+                t, _, sp = t.partition("/")          # "71" or "71/2" (tile / split)
                 try:
-                    row.append("t%s %.1f" % (t, timeit(tile=int(t), split=1)))
+                    row.append("t%s%s %.1f" % (t, "/" + sp if sp else "", timeit(tile=int(t), split=int(sp or 1))))
                 except RuntimeError as e:
                     row.append("t%s n/a" % t)
             print("    " + "  ".join(row))
