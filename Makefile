@@ -10,9 +10,12 @@ CXXFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Igeo4d_amd/cs
 
 all: $(LIB)
 
-build/%.o: geo4d_amd/csrc/%.hip geo4d_amd/csrc/common.h geo4d_amd/csrc/gemm_kernel.h geo4d_amd/csrc/gemm_kernel_v2.h geo4d_amd/csrc/gemm_kernel_v3.h include/geo4d_hip.h
+# header dependencies per translation unit (-MMD): editing one GEMM generation's header rebuilds only the units that include it
+build/%.o: geo4d_amd/csrc/%.hip
 	@mkdir -p build
-	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+	$(HIPCC) $(CXXFLAGS) -MMD -MP -MF build/$*.d -c $< -o $@
+
+-include $(OBJ:.o=.d)
 
 $(LIB): $(OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJ) -o $@

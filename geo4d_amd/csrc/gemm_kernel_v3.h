@@ -31,7 +31,7 @@ extern template int launch_v2_typed<bf16_t>(const geo4d_conv_gemm_t&, hipStream_
 extern template int launch_v2_typed<f16_t>(const geo4d_conv_gemm_t&, hipStream_t);
 
 template <int BM, int BN>
-constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH + BM * MAXTAP * 4; }
+constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH; }
 
 #define GEO4D_V3_BAR()                          \
     do {                                        \
@@ -39,8 +39,23 @@ constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH + BM * MAXTAP * 4; 
         __builtin_amdgcn_s_barrier();           \
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
+// the K loop's barrier / wait (ablation 7 / 6 drop them)
+#define GEO4D_V3_LBAR()                         \
+    do {                                        \
+        if constexpr (ABL != 7) GEO4D_V3_BAR(); \
+        else __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+#define GEO4D_V3_WAIT()                                                                          \
+    do {                                                                                         \
+        if constexpr (ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");   \
+    } while (0)
 
-template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
+// ABL (profiling builds only, tile hints 80..99, WRONG results by construction): 1 = no LDS-DMA inside the K loop, 2 = no MFMA, 3 = no
+// stagger of the wave groups, 4 = staging cursor frozen (no advance / table fetch), 5 = no fragment reads, 6 = no DMA waits, 7 = no barriers;
+// 8 = CORRECT results plus s_memtime stamps of waves 0 and 4 of workgroup 0 (4 per phase, slabs 8..23 of its first tile) -> p.workspace
+// DA: the two A halves own separate fragment registers, so that the NEXT slab's A0 fragments are read in phase 3 (6 + 4 + 4 + 6 reads per
+// phase on the 160x320 tile instead of 12 + 4 + 4 + 0); off for 256x256, whose 128 accumulators leave no room for it
+template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false, int ABL = 0, bool DA = (BM * BN < 256 * 256)>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
 __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm_t p, const int splits, const int tiles_mn) {
     static_assert(WM * WN == 8, "two groups of four waves");
     static_assert(!std::is_same<T, float>::value, "v3 serves the 16-bit MFMA forms (bf16, f16, bf16x3)");
@@ -58,7 +73,6 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     // issued more has more than NWAIT younger pieces outstanding, for which vmcnt(NWAIT) is the stricter wait.
     constexpr int NWAIT = RA0 / 64 + RA1 / 64 + RB0 / 64 + RB1 / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* rowpix = (int*)(smem + 2 * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,51 +86,105 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     const long G = gridDim.x;
     const bool direct_rows = ntap == 1 && p.stride == 1 && p.ups == 1 && p.ph == 0 && p.pw == 0 && p.pt == 0 && p.Hin * p.Win == hw;
     const int ns = p.K / BK / splits;                  // slabs per tile: the host guarantees an even split and ns >= 2
-    const T* __restrict__ Z = (const T*)p.zeros;
     const int ccol = tid & 7;
     const int r0 = tid >> 3;
 
-    // ---- staging side: LDS row r0 + 64 j of a half panel <-> tile row, source-side swizzle ----------------------------------------
+    // ---- staging side -----------------------------------------------------------------------------------------------------------------
+    // Every LDS-DMA piece is a `buffer_load_dwordx4 ... lds` on a raw buffer resource (base + 2 GB window in SGPRs): the per-lane part
+    // of the address is a 32-bit byte offset that is CONSTANT for a tile (row x pitch + swizzled chunk), the per-slab part (tap, channel
+    // slab) is a wave-uniform SGPR offset. A lane whose tap falls into zero padding (or whose row is beyond M / N) offers an offset
+    // beyond the window: the hardware writes zeros for it (tools/probe/bufload_probe.hip). What this replaces: a gather table in LDS
+    // plus ~25 VALU instructions per piece and slab of 64-bit pointer arithmetic - measured 1100-1700 cycles per slab in the MFMA
+    // segment that followed it (profiles/r03_gemm_v3_timeline.md), i.e. the longest segment of the whole loop.
+    constexpr unsigned OOB = 0x80000000u;              // = num_records of both resources
+    constexpr int ESZ = 16 / EPC;                      // bytes per element (bf16x3 stores f32)
     auto tile_row = [&](int r, int rows, int per_wave, int wt, int off) { return r < rows ? (r / per_wave) * wt + off + r % per_wave : -1; };
     auto rowA = [&](int h, int j) { return h ? tile_row(r0 + 64 * j, RA1, MB1 * 16, WTM, MB0 * 16) : tile_row(r0 + 64 * j, RA0, MB0 * 16, WTM, 0); };
     auto rowB = [&](int h, int j) { return h ? tile_row(r0 + 64 * j, RB1, NB1 * 16, WTN, NB0 * 16) : tile_row(r0 + 64 * j, RB0, NB0 * 16, WTN, 0); };
     auto chunk = [&](int j) { return (ccol ^ swz_key<T>(r0 + 64 * j)) * EPC; };   // LDS slot `ccol` of panel row r holds chunk ccol ^ key(r)
+    const int khw = p.KH * p.KW;
 
-    // staging cursor (two slabs ahead of the MFMAs, across tiles) and the tile it is in
+    // staging cursors (two slabs ahead of the MFMAs, across tiles) and the tile they are in
     long wS = 0;
     bool validS = false;
     int tmS = 0, tnS = 0, kzS = 0;
     long bzS = 0;
-    const T* __restrict__ A_S = nullptr;               // activation base of the A cursor's tile
-    const T* __restrict__ A_N = nullptr;               // ... of the tile the B cursor already moved to
-    bool validA = false;                               // the A cursor's tile (it follows the B cursor one phase later)
-    int tmA = 0;
-    int tapA = 0, c0A = 0, tapB = 0, c0B = 0, tap_beg = 0, c0_beg = 0;
-    const T* arow[2][PA0];                             // source of this thread's chunk of the A cursor's slab (without c0A); null = zeros
-    const T* wrow[2][PB0];                             // weight rows of the B cursor's tile (without the K offset)
-
-    auto fetch_A = [&]() {
+    unsigned voffA[2][PA0], maskA[2][PA0];             // per lane: byte offset of (row's tap-0 pixel, chunk) in the A window; valid-tap bits
+    unsigned voffB[2][PB0];                            // per lane: byte offset of (weight row, chunk) in the B window, OOB beyond N
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.zeros, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = rA;
+    // A cursor: tap (kt, ky, kx) and channel slab -> SGPR byte offset + bit index of the tap; B cursor: the same for the weight's K axis
+    int ktA = 0, kyA = 0, kxA = 0, c0A = 0, tapB = 0, c0B = 0, tap_beg = 0, c0_beg = 0;
+    unsigned soffA = 0, bitA = 0, soffB = 0;
+    auto refresh_A = [&]() {
+        soffA = (unsigned)((((long)ktA * p.Hin + kyA) * p.Win + kxA) * p.lda + c0A) * ESZ;
+        bitA = (unsigned)((ktA * p.KH + kyA) * p.KW + kxA);
+    };
+    auto refresh_B = [&]() { soffB = (unsigned)(tapB * p.Cin + c0B) * ESZ; };
+    auto begin_A = [&]() {                             // cursor at the tile's first slab
+        ktA = tap_beg / khw;
+        const int r2 = tap_beg - ktA * khw;
+        kyA = r2 / p.KW;
+        kxA = r2 - kyA * p.KW;
+        c0A = c0_beg;
+        refresh_A();
+    };
+    auto step_A = [&]() {                              // K order: channel-slab major, tap minor
+        if (++kxA == p.KW) {
+            kxA = 0;
+            if (++kyA == p.KH) {
+                kyA = 0;
+                if (++ktA == p.KT) {
+                    ktA = 0;
+                    c0A += BK;
+                }
+            }
+        }
+        refresh_A();
+    };
+    auto step_B = [&]() {
+        if (++tapB == ntap) {
+            tapB = 0;
+            c0B += BK;
+        }
+        refresh_B();
+    };
+    // the A window of tile (tm_, bz_): base = the tap-0 source pixel of the tile's first row (the smallest address any of its rows
+    // reads; it may lie before the tensor when that pixel is padding - only in-image taps are ever dereferenced)
+    auto tap0_pixel = [&](int m) -> long {
+        const int f = m / hw, rem = m - f * hw;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        return ((long)(f - p.pt) * p.Hin + (oy * p.stride - p.ph)) * p.Win + (ox * p.stride - p.pw);
+    };
+    auto window_A = [&](bool valid, int tm_, long bz_) {
+        const long P0 = valid ? tap0_pixel(tm_ * BM) : 0;
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + bz_ * p.a_bs + P0 * p.lda), 0, OOB, 0x00020000);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < (h ? PA1 : PA0); ++j) {
                 const int row = rowA(h, j);
-                const T* ptr = nullptr;
-                if (row >= 0 && validA) {
-                    int px;
-                    if (direct_rows) {
-                        const int m = tmA * BM + row;
-                        px = m < p.M ? m : -1;
-                    } else {
-                        px = rowpix[row * ntap + tapA];
-                    }
-                    if (px >= 0) ptr = A_S + (long)px * p.lda + chunk(j);
+                const int m = tm_ * BM + row;
+                unsigned off = 0, mask = 0;
+                if (valid && row >= 0 && m < p.M) {
+                    const int f = m / hw, rem = m - f * hw;
+                    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                    const int iy0 = oy * p.stride - p.ph, ix0 = ox * p.stride - p.pw, ft = (f % p.T) - p.pt;
+                    const long px0 = ((long)(f - p.pt) * p.Hin + iy0) * p.Win + ix0;
+                    off = (unsigned)(((px0 - P0) * p.lda + chunk(j)) * ESZ);
+                    unsigned bit = 1;
+                    for (int kt = 0; kt < p.KT; ++kt)
+                        for (int ky = 0; ky < p.KH; ++ky)
+                            for (int kx = 0; kx < p.KW; ++kx, bit <<= 1)
+                                if ((unsigned)(ft + kt) < (unsigned)p.T && (unsigned)(iy0 + ky) < (unsigned)p.Hin && (unsigned)(ix0 + kx) < (unsigned)p.Win)
+                                    mask |= bit;
                 }
-                arow[h][j] = ptr;
+                voffA[h][j] = off;
+                maskA[h][j] = mask;
             }
         }
     };
-    // moves the staging tile to w_ (B side at once, A side at the next advance_A): ids, weight rows, gather table
+    // moves the staging tile to w_: ids and the B window at once, the A window at the next advance_A (one phase later)
     auto stage_tile = [&](long w_) {
         wS = w_;
         validS = w_ < total;
@@ -124,7 +192,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < PB0; ++j) wrow[h][j] = nullptr;
+                for (int j = 0; j < PB0; ++j) voffB[h][j] = OOB;     // the stream's tail stages zeros
             return;
         }
         const long t = w_ % tiles_mn, rest = w_ / tiles_mn;
@@ -132,43 +200,18 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         kzS = (int)(rest / p.batch);
         tmS = (int)(t / tiles_n);
         tnS = (int)(t - (long)tmS * tiles_n);
-        A_N = (const T*)p.A + bzS * p.a_bs;
-        const T* __restrict__ W = (const T*)p.W + bzS * p.w_bs;
+        rB = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + bzS * p.w_bs + (long)tnS * BN * p.ldw), 0, OOB, 0x00020000);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < (h ? PB1 : PB0); ++j) {
                 const int row = rowB(h, j);
-                const int n = tnS * BN + row;
-                wrow[h][j] = (row >= 0 && n < p.N) ? W + (long)n * p.ldw + chunk(j) : nullptr;
+                voffB[h][j] = (row >= 0 && tnS * BN + row < p.N) ? (unsigned)(((long)row * p.ldw + chunk(j)) * ESZ) : OOB;
             }
         }
         const int s_begin = kzS * ns;
         tap_beg = s_begin % ntap;
         c0_beg = (s_begin / ntap) * BK;
-        if (!direct_rows) {
-            // gather table: source pixel of (tile row, tap), -1 = zero padding. The previous tile's table is dead: its last fetch
-            // ran three phases ago. Visible to fetch_A one phase later (lgkmcnt(0) here, then the phase's barriers).
-            const int hlim = p.ups == 2 ? 2 * p.Hin : p.Hin, wlim = p.ups == 2 ? 2 * p.Win : p.Win;
-            const int ush = p.ups == 2 ? 1 : 0;
-            for (int e = tid; e < BM * ntap; e += 512) {
-                const int row = e / ntap, tp = e - row * ntap;
-                const int m = tmS * BM + row;
-                int px = -1;
-                if (m < p.M) {
-                    const int f = m / hw, rem = m - f * hw;
-                    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                    const int kt = tp / (p.KH * p.KW), r2 = tp - kt * (p.KH * p.KW);
-                    const int ky = r2 / p.KW, kx = r2 - ky * p.KW;
-                    const int iy = oy * p.stride - p.ph + ky, ix = ox * p.stride - p.pw + kx;
-                    const int tt = (f % p.T) + kt - p.pt;
-                    if ((unsigned)iy < (unsigned)hlim && (unsigned)ix < (unsigned)wlim && (unsigned)tt < (unsigned)p.T)
-                        px = ((f + kt - p.pt) * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
-                }
-                rowpix[e] = px;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
     };
     // one LDS-DMA piece per 8 panel rows and wave: wave-uniform destination + lane * 16 B
     auto issue_A = [&](auto hc, int st) {
@@ -178,9 +221,8 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
         for (int j = 0; j < (H ? PA1 : PA0); ++j) {
             if ((j + 1) * 64 <= R || wave * 8 + j * 64 < R) {
-                const T* src = arow[H][j] ? arow[H][j] + c0A : Z;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(base + j * 64 * PITCH), 16, 0, 0);
+                const unsigned v = ((maskA[H][j] >> bitA) & 1u) ? voffA[H][j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + j * 64 * PITCH), 16, (int)v, (int)soffA, 0, 0);
             }
         }
     };
@@ -188,14 +230,10 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         constexpr int H = decltype(hc)::value;
         constexpr int R = H ? RB1 : RB0;
         char* base = smem + st * STAGE + (H ? OB1 : OB0) + wave * 1024;
-        const long koff = (long)tapB * p.Cin + c0B;
 #pragma unroll
         for (int j = 0; j < (H ? PB1 : PB0); ++j) {
-            if ((j + 1) * 64 <= R || wave * 8 + j * 64 < R) {
-                const T* src = wrow[H][j] ? wrow[H][j] + koff : Z;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(base + j * 64 * PITCH), 16, 0, 0);
-            }
+            if ((j + 1) * 64 <= R || wave * 8 + j * 64 < R)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + j * 64 * PITCH), 16, (int)voffB[H][j], (int)soffB, 0, 0);
         }
     };
     // after B1 of slab t + 1: the B cursor moves to slab t + 2, which opens the next tile when t + 2 == ns
@@ -204,26 +242,18 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             stage_tile(wS + G);
             tapB = tap_beg;
             c0B = c0_beg;
-        } else if (++tapB == ntap) {
-            tapB = 0;
-            c0B += BK;
+            refresh_B();
+        } else {
+            step_B();
         }
     };
-    // after A1 of slab t + 1: the same for the A cursor (a new tile's table was written one phase ago)
+    // after A1 of slab t + 1: the same for the A cursor
     auto advance_A = [&](int t) {
         if (t + 2 == ns) {
-            A_S = A_N;
-            validA = validS;
-            tmA = tmS;
-            tapA = tap_beg;
-            c0A = c0_beg;
-            fetch_A();
+            window_A(validS, tmS, bzS);
+            begin_A();
         } else {
-            if (++tapA == ntap) {
-                tapA = 0;
-                c0A += BK;
-            }
-            if (!direct_rows) fetch_A();
+            step_A();
         }
     };
 
@@ -240,15 +270,15 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         foff[1] = lr * PITCH + (((4 + lq) ^ fkey) << 4);
     }
     const bool a_split = HOT ? (HOT == 2) : (p.a_split != 0), w_split = HOT ? true : (p.w_split != 0);
-    u32x4 fa[2][MB0];                                  // the A half in use: [bf16x3: hi | lo; 16-bit: K half][block]
+    u32x4 fa[DA ? 2 : 1][2][MB0];                      // A fragments [half (one shared set without DA)][bf16x3: hi | lo; 16-bit: K half][block]
     u32x4 fb[2][2][NB0];                               // both B halves (C0 is used again by the slab's last phase)
     auto read_A = [&](auto hc, const char* sb) {
         constexpr int H = decltype(hc)::value;
         const char* base = sb + (H ? OA1 : OA0) + wr * ((H ? MB1 : MB0) * 16) * PITCH;
 #pragma unroll
         for (int a = 0; a < (H ? MB1 : MB0); ++a) {
-            fa[0][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[0]);
-            fa[1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);
+            fa[DA ? H : 0][0][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[0]);
+            fa[DA ? H : 0][1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);
         }
     };
     auto read_B = [&](auto hc, const char* sb) {
@@ -267,8 +297,8 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             if (!a_split) {
 #pragma unroll
                 for (int a = 0; a < (H ? MB1 : MB0); ++a) {
-                    const u32x4 x0 = fa[0][a], x1 = fa[1][a];
-                    split8_bf16(x0, x1, fa[0][a], fa[1][a]);
+                    const u32x4 x0 = fa[DA ? H : 0][0][a], x1 = fa[DA ? H : 0][1][a];
+                    split8_bf16(x0, x1, fa[DA ? H : 0][0][a], fa[DA ? H : 0][1][a]);
                 }
             }
         }
@@ -290,6 +320,19 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     auto mma_quadrant = [&](auto hac, auto hbc) {
         constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
         constexpr int MBH = HA ? MB1 : MB0, NBH = HB ? NB1 : NB0, AO = HA ? MB0 : 0, BO = HB ? NB0 : 0;
+        if constexpr (ABL == 2) {                       // keep the fragments live, skip the matrix pipe
+#pragma unroll
+            for (int a = 0; a < MBH; ++a) asm volatile("" ::"v"(fa[DA ? HA : 0][0][a]), "v"(fa[DA ? HA : 0][1][a]));
+#pragma unroll
+            for (int b = 0; b < NBH; ++b) asm volatile("" ::"v"(fb[HB][0][b]), "v"(fb[HB][1][b]));
+            return;
+        }
+        if constexpr (ABL == 5) {                       // stale fragments: keep the registers opaque
+#pragma unroll
+            for (int a = 0; a < MBH; ++a) asm volatile("" : "+v"(fa[DA ? HA : 0][0][a]), "+v"(fa[DA ? HA : 0][1][a]));
+#pragma unroll
+            for (int b = 0; b < NBH; ++b) asm volatile("" : "+v"(fb[HB][0][b]), "+v"(fb[HB][1][b]));
+        }
         __builtin_amdgcn_s_setprio(1);
         if constexpr (IsX3<T>::value) {
 #pragma unroll
@@ -299,7 +342,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
                     for (int a = 0; a < MBH; ++a) {
                         const u32x4& wv = fb[HB][term == 0 ? 1 : 0][b];
-                        const u32x4& av = fa[term == 1 ? 1 : 0][a];
+                        const u32x4& av = fa[DA ? HA : 0][term == 1 ? 1 : 0][a];
                         acc[AO + a][BO + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, av),
                                                                                       acc[AO + a][BO + b], 0, 0, 0);
                     }
@@ -311,7 +354,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
                 for (int b = 0; b < NBH; ++b) {
 #pragma unroll
-                    for (int a = 0; a < MBH; ++a) mma16<T>(acc[AO + a][BO + b], fb[HB][h][b], fa[h][a]);
+                    for (int a = 0; a < MBH; ++a) mma16<T>(acc[AO + a][BO + b], fb[HB][h][b], fa[DA ? HA : 0][h][a]);
                 }
             }
         }
@@ -320,38 +363,40 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
     const bool partial = splits > 1;                   // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
+    unsigned long long* tl = (unsigned long long*)(smem + 2 * STAGE);   // ABL 8: [group][slab 8..23][16 stamps]
+    bool first_tile = true;
+    auto stamp = [&](int t, int idx) {
+        if constexpr (ABL == 8) {
+            if (blockIdx.x == 0 && first_tile && (wave & 3) == 0 && t >= 8 && t < 24) {
+                const unsigned long long c = __builtin_amdgcn_s_memtime();
+                if (lane == 0) tl[(grp * 16 + (t - 8)) * 16 + idx] = c;
+            }
+        }
+    };
 
-    // ---- first tile: table, then the steady state's in-flight set A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ----------------------------------
+    // ---- first tile: windows, then the steady state's in-flight set A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) --------------------------------
     const long w0 = xcd_remap((long)blockIdx.x, G);    // each XCD walks a contiguous range of every round of G tiles
     if (w0 >= total) return;
     stage_tile(w0);
-    __syncthreads();
-    A_S = A_N;
-    validA = true;
-    tmA = tmS;
-    tapA = tapB = tap_beg;
-    c0A = c0B = c0_beg;
-    fetch_A();
-    auto step_cursor = [&](int& tap, int& c0) {
-        if (++tap == ntap) {
-            tap = 0;
-            c0 += BK;
-        }
-    };
+    window_A(true, tmS, bzS);
+    begin_A();
+    tapB = tap_beg;
+    c0B = c0_beg;
+    refresh_B();
     issue_A(H0{}, 0);
     issue_B(H0{}, 0);
     issue_B(H1{}, 0);
-    step_cursor(tapB, c0B);
+    step_B();
     issue_A(H1{}, 0);
-    step_cursor(tapA, c0A);
-    if (!direct_rows) fetch_A();
+    step_A();
     issue_A(H0{}, 1);
     issue_B(H0{}, 1);
     int tmC = tmS, tnC = tnS, kzC = kzS;               // the tile the MFMAs are in
     long bzC = bzS;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
     __syncthreads();
-    if (grp == 1) GEO4D_V3_BAR();
+    if constexpr (DA) read_A(H0{}, smem);              // A0 fragments of slab 0 (afterwards phase 3 reads the next slab's)
+    if (grp == 1 && ABL != 3) GEO4D_V3_BAR();
 
     int g = 0;                                         // ring stage of the current slab (slabs are counted across tiles)
     while (true) {
@@ -361,39 +406,62 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < ns; ++t, g ^= 1) {
             const char* sb = smem + g * STAGE;
-            // phase 0: fragments A0, B0 | B1 of slab t + 1 | quadrant (R0, C0)
-            read_A(H0{}, sb);
-            read_B(H0{}, sb);
-            issue_B(H1{}, g ^ 1);
-            advance_B(t);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");    // B1 of this slab
-            GEO4D_V3_BAR();
+            // Every phase: [issue one half panel of a future slab | read the fragments this or the next phase needs | counted wait]
+            // barrier [quadrant MFMAs | cursor / pointer work for the NEXT phase's issue] barrier. The wait of phase k retires the half
+            // panel whose fragments are read in phase k + 1 (A0 of slab t + 1 in phase 2 when DA reads it in phase 3).
+            // phase 0: quadrant (R0, C0) | B1 of slab t + 1
+            stamp(t, 0);
+            if constexpr (ABL != 1) issue_B(H1{}, g ^ 1);
+            if constexpr (ABL != 5) {
+                if constexpr (!DA) read_A(H0{}, sb);
+                read_B(H0{}, sb);
+            }
+            GEO4D_V3_WAIT();
+            stamp(t, 1);
+            GEO4D_V3_LBAR();
+            stamp(t, 2);
             split_A(H0{});
             split_B(H0{});
             mma_quadrant(H0{}, H0{});
-            GEO4D_V3_BAR();
-            // phase 1: fragments B1 | A1 of slab t + 1 | quadrant (R0, C1)
-            read_B(H1{}, sb);
-            issue_A(H1{}, g ^ 1);
-            advance_A(t);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");    // A1 of this slab
-            GEO4D_V3_BAR();
+            if (ABL != 4 || t + 2 == ns) advance_B(t);
+            stamp(t, 3);
+            GEO4D_V3_LBAR();
+            // phase 1: quadrant (R0, C1) | A1 of slab t + 1
+            stamp(t, 4);
+            if constexpr (ABL != 1) issue_A(H1{}, g ^ 1);
+            if constexpr (ABL != 5) read_B(H1{}, sb);
+            GEO4D_V3_WAIT();
+            stamp(t, 5);
+            GEO4D_V3_LBAR();
+            stamp(t, 6);
             split_B(H1{});
             mma_quadrant(H0{}, H1{});
-            GEO4D_V3_BAR();
-            // phase 2: fragments A1 | A0 of slab t + 2 | quadrant (R1, C1)
-            read_A(H1{}, sb);
-            issue_A(H0{}, g);
-            GEO4D_V3_BAR();
+            if (ABL != 4 || t + 2 == ns) advance_A(t);
+            stamp(t, 7);
+            GEO4D_V3_LBAR();
+            // phase 2: quadrant (R1, C1) | A0 of slab t + 2
+            stamp(t, 8);
+            if constexpr (ABL != 1) issue_A(H0{}, g);
+            if constexpr (ABL != 5) read_A(H1{}, sb);
+            GEO4D_V3_WAIT();
+            stamp(t, 9);
+            GEO4D_V3_LBAR();
+            stamp(t, 10);
             split_A(H1{});
             mma_quadrant(H1{}, H1{});
-            GEO4D_V3_BAR();
-            // phase 3: no new fragments | B0 of slab t + 2 | quadrant (R1, C0)
-            issue_B(H0{}, g);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");    // A0, B0 of slab t + 1
-            GEO4D_V3_BAR();
+            stamp(t, 11);
+            GEO4D_V3_LBAR();
+            // phase 3: quadrant (R1, C0) | B0 of slab t + 2 | with DA: the A0 fragments of slab t + 1 (other ring stage)
+            stamp(t, 12);
+            if constexpr (ABL != 1) issue_B(H0{}, g);
+            if constexpr (ABL != 5 && DA) read_A(H0{}, smem + (g ^ 1) * STAGE);
+            GEO4D_V3_WAIT();
+            stamp(t, 13);
+            GEO4D_V3_LBAR();
+            stamp(t, 14);
             mma_quadrant(H1{}, H0{});
-            if (t + 1 < ns) GEO4D_V3_BAR();
+            stamp(t, 15);
+            if (t + 1 < ns) GEO4D_V3_LBAR();
         }
         // the tile's closing barrier, then the epilogue (group 1's runs beside group 0's next fragment reads / DMA issue).
         // (Putting group 1's epilogue BEFORE the barrier so that both share one interval makes the register allocator spill ~900
@@ -403,20 +471,25 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         // a REAL s_waitcnt vmcnt(0) (the builtin, which the compiler's wait-count pass tracks; an inline-asm one it does not see):
         // without it the pass has to assume pending loads into VGPRs at the K loop's header and drains the DMA queue every slab
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        first_tile = false;
         if (!validS) break;                            // the staging tile is the next tile of the MFMAs
         tmC = tmS; tnC = tnS; kzC = kzS; bzC = bzS;
     }
-    if (grp == 0) GEO4D_V3_BAR();
+    if (grp == 0 && ABL != 3) GEO4D_V3_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy pieces of the stream's tail must land before the LDS is released
+    if constexpr (ABL == 8) {
+        __syncthreads();
+        if (blockIdx.x == 0 && p.workspace) ((unsigned long long*)p.workspace)[tid] = tl[tid];    // 2 x 16 x 16 stamps
+    }
 }
 
 // one workgroup per CU (96-155 KB of LDS); persistent over the tile list
-template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false>
+template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false, int ABL = 0>
 int launch_v3_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
-    constexpr int smem = v3_smem_bytes<BM, BN>();
+    constexpr int smem = v3_smem_bytes<BM, BN>() + (ABL == 8 ? 4096 : 0);
     static_assert(smem <= 160 * 1024, "LDS");
     static int resident = 0;
-    auto kern = conv_gemm_v3_kernel<T, BM, BN, WM, WN, HOT, OSPLIT>;
+    auto kern = conv_gemm_v3_kernel<T, BM, BN, WM, WN, HOT, OSPLIT, ABL>;
     if (!resident) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
@@ -467,8 +540,8 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 
 // tile hints 71..74: phased K loop on 8 waves (2 x 4), one workgroup per CU
 //   71: 256x256 (wave tiles 128x64)   72: 160x320 (80x80)   73: 256x128 (128x32)   74: 128x256 (64x64)
-// Launches the phased stream cannot take (fewer than 2 slabs per tile, an uneven split-K, outputs that are not 4-element aligned)
-// fall back to the second-generation tile of the same shape.
+// Launches the phased stream cannot take (fewer than 2 slabs per tile, an uneven split-K, outputs that are not 4-element aligned,
+// nearest-upsampling gathers, operands beyond the 2 GB buffer window) fall back to the second-generation tile of the same shape.
 template <typename T>
 int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     if constexpr (std::is_same<T, float>::value) {
@@ -488,6 +561,24 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             }
             sp = p.split_k;
         }
+#ifdef GEO4D_GEMM_ABLATION   // profiling build (make ABLATION=1): 80 + a = 160x320, 90 + a = 256x256 with ablation a, pre-split x pre-split bf16x3 only
+        if constexpr (IsX3<T>::value) {
+            if (p.w_split && p.a_split && !p.o_split) switch (p.tile_hint) {
+#define GEO4D_ABL3(base, BM_, BN_)                                                                        \
+                case base + 1: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 1>(p, sp, stream); \
+                case base + 2: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 2>(p, sp, stream); \
+                case base + 3: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 3>(p, sp, stream); \
+                case base + 4: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 4>(p, sp, stream); \
+                case base + 5: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 5>(p, sp, stream); \
+                case base + 6: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 6>(p, sp, stream); \
+                case base + 7: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 7>(p, sp, stream); \
+                case base + 8: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 8>(p, sp, stream);
+                GEO4D_ABL3(80, 160, 320)
+                GEO4D_ABL3(90, 256, 256)
+#undef GEO4D_ABL3
+            }
+        }
+#endif
         if (p.tile_hint < 71 || p.tile_hint > 74) {
             geo4d_set_error("conv_gemm: unknown tile_hint");
             return GEO4D_EINVAL;
@@ -503,7 +594,12 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             vec_ok = vec_ok && (p.ldo & 3) == 0 && ((uintptr_t)p.O % (4 * oesz)) == 0 && (p.batch == 1 || (p.o_bs & 3) == 0);
             if (p.R) vec_ok = vec_ok && (p.ldr & 3) == 0 && ((uintptr_t)p.R % (4 * oesz)) == 0 && (p.batch == 1 || (p.r_bs & 3) == 0);
         }
-        if (nslab % sp || nslab / sp < 2 || !vec_ok) {
+        // the staging side addresses each operand through a 2 GB buffer window per tile (see the kernel): nearest-upsampling gathers have
+        // no uniform tap offsets, and a tile's rows plus its taps must stay inside the window
+        const long esz = 16 / Elem<T>::EPC;
+        const long frames = 256 / ((long)p.Hout * p.Wout) + 2 + p.KT;
+        const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
+        if (nslab % sp || nslab / sp < 2 || !vec_ok || !window_ok) {
             geo4d_conv_gemm_t q = p;
             q.tile_hint = p.tile_hint == 71 ? 22 : p.tile_hint == 72 ? 23 : p.tile_hint == 73 ? 21 : 29;
             return launch_v2_typed<T>(q, stream);
@@ -519,5 +615,7 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
 }
 
 #undef GEO4D_V3_BAR
+#undef GEO4D_V3_LBAR
+#undef GEO4D_V3_WAIT
 
 }  // namespace geo4d_gemm
