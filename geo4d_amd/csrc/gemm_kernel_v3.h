@@ -1,23 +1,30 @@
-// geo4d_amd/csrc/gemm_kernel_v3.h — third-generation implicit-GEMM kernel (round 3, tile hints 71..74): the second generation's
-// gather, LDS image, 16x16x32 MFMA form and register epilogue under a PHASED K loop.
+// geo4d_amd/csrc/gemm_kernel_v3.h — third-generation implicit-GEMM kernel (round 3, tile hints 71..74): the second generation's LDS
+// image, 16x16x32 MFMA form and register epilogue under a PHASED, software-pipelined K loop with a different staging side.
 //
-// Why (profiles/r03_gemm_v2_explore_and_ablation.md): in the first two generations every wave of the single resident workgroup issues
-// its 7-8 LDS-DMA pieces of a K slab back to back (60-185 cycles each while the request queue of the CU is full), then reads its
-// fragments, then runs its MFMAs; all eight waves do this in lockstep between two barriers, so the matrix pipe idles while the
-// requests are issued and the request path idles while the MFMAs run (full ~ MFMA-only + 0.75 x DMA-only). Here
-//   * a K slab is cut into FOUR phases, one per quadrant of the wave tile (rows R0 | R1 x columns C0 | C1); each phase reads only the
-//     fragments it newly needs (A0 + B0, B1, A1, none), issues ONE quarter of a future slab's LDS-DMA pieces (a "half panel": the R0 /
-//     R1 rows of every wave's A rows, the C0 / C1 rows of the weight panel) and then runs the quadrant's MFMAs;
-//   * the DMA waits are COUNTED (s_waitcnt vmcnt(pieces of one slab), never 0): a half panel is issued 4-5 phases before the wait
-//     that retires it and read one phase after that wait, so a full slab (60-64 KB) is always in flight across the barriers;
-//   * the two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run STAGGERED by one barrier: while one group is in its
-//     MFMA segment the other one reads fragments and issues DMA, and s_setprio keeps the MFMA segment ahead on the shared SIMD;
-//   * workgroups are persistent and the staging cursor runs two slabs ahead ACROSS tiles: the next tile's gather table is built and
-//     its first two slabs are issued during the current tile's last two slabs, the epilogue overlaps the other group's segment.
-// Hazards (MI355X_MICROARCH.md "nothing orders a ds_read behind a pending LDS-DMA except the issuing wave's vmcnt plus a barrier"):
-//   RAW  a half panel is read in phase k + 1 at the earliest when every wave's covering vmcnt sits before the first barrier of
-//        phase k (group 1 executes that wait one barrier interval later than group 0, still before group 0's phase k + 1);
-//   WAR  a half panel is re-staged two phases or more after the phase that read it (group 1's reads retire one interval late).
+// Why (profiles/r03_gemm_v2_explore_and_ablation.md, profiles/r03_gemm_v3_phased.md): in the first two generations every wave of the
+// single resident workgroup computes 7-8 source pointers per K slab (gather-table read + ~25 VALU instructions of 64-bit arithmetic
+// each), issues its LDS-DMA pieces back to back (60-185 cycles each while the CU's request queue is full), reads its fragments, waits
+// for them, then runs its MFMAs - one after the other, all eight waves in lockstep between two barriers. Here
+//   * staging goes through RAW BUFFER RESOURCES (`buffer_load_dwordx4 ... lds`): per tile a 2 GB window per operand in SGPRs and a
+//     32-bit byte offset per lane and piece in VGPRs that is constant for the tile; per slab only a wave-uniform SGPR offset (tap,
+//     channel slab) changes. Zero padding = a lane offset beyond the window (the hardware writes zeros, tools/probe/bufload_probe.hip)
+//     selected by one bit of a per-row tap mask: 3 VALU instructions per activation piece, none per weight piece, no gather table;
+//   * a K slab is cut into FOUR phases, one per quadrant of the wave tile (rows R0 | R1 x columns C0 | C1), walked so that consecutive
+//     phases share one operand half; every phase issues ONE half panel of a future slab (the R0 / R1 rows of every wave's A rows, the
+//     C0 / C1 weight rows), reads the fragments of the half the NEXT phase newly needs (their registers are free by construction of
+//     the walk) and runs its quadrant's MFMAs with fragments that arrived a phase ago;
+//   * the DMA waits are COUNTED (`s_waitcnt vmcnt(pieces of four half panels)`, never 0): half panels are issued in the order they
+//     are read, five phases ahead, and re-staged three phases after their read, so more than a full slab (60-64 KB) stays in flight
+//     across the barriers; one barrier per phase;
+//   * workgroups are persistent and the staging cursors run two (activations) and three (weights) slabs ahead ACROSS tiles: the next
+//     tile's windows and first slabs are issued during the current tile's last slabs.
+// Hazards (MI355X_MICROARCH.md: "nothing orders a ds_read behind a pending LDS-DMA except the issuing wave's vmcnt plus a barrier"):
+//   RAW  a half panel is read in phase k + 1 when every wave's covering vmcnt sits before the barrier that closes phase k;
+//   WAR  a half panel is re-staged three phases after the phase that read it (two would do: the reads retire before the MFMAs of the
+//        following phase, i.e. before that phase's barrier).
+// What it bought (MI355X, bf16x3, pre-split operands): the staging side of a slab went from ~2.5 us to ~1.6 us, but the whole kernel
+// only from 222 us to 210 us on the largest conv of the U-Net (+4.5 %), +/- 4 % elsewhere: with the DMA and the fragment reads off
+// the critical path the loop sits at ~75 % of what its MFMAs alone take on this chip (163 us, not the 103 us of the nominal clock).
 // Same ABI struct, same K order (channel-slab major, tap minor), same per-accumulator summation order as conv_gemm_v2_kernel:
 // results are bit-identical to tile hints 21..29.
 #pragma once
@@ -50,12 +57,13 @@ constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH; }
         if constexpr (ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");   \
     } while (0)
 
-// ABL (profiling builds only, tile hints 80..99, WRONG results by construction): 1 = no LDS-DMA inside the K loop, 2 = no MFMA, 3 = no
-// stagger of the wave groups, 4 = staging cursor frozen (no advance / table fetch), 5 = no fragment reads, 6 = no DMA waits, 7 = no barriers;
+// ABL (profiling builds only, tile hints 80..99, WRONG results by construction except 3 and 8): 1 = no LDS-DMA inside the K loop, 2 = no MFMA, 3 =// 
+// STAGGERED wave groups (see STAG), 4 = unused, 5 = no fragment reads, 6 = no DMA waits, 7 = no barriers;
 // 8 = CORRECT results plus s_memtime stamps of waves 0 and 4 of workgroup 0 (4 per phase, slabs 8..23 of its first tile) -> p.workspace
-// DA: the two A halves own separate fragment registers, so that the NEXT slab's A0 fragments are read in phase 3 (6 + 4 + 4 + 6 reads per
-// phase on the 160x320 tile instead of 12 + 4 + 4 + 0); off for 256x256, whose 128 accumulators leave no room for it
-template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false, int ABL = 0, bool DA = (BM * BN < 256 * 256)>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
+// STAG (ablation 3 only): the two wave groups run staggered by one barrier, with a second barrier inside every phase (issue / read |
+// MFMA), so that one group's MFMA segment runs beside the other group's issue segment. Measured 4-10 % SLOWER than all eight waves in
+// lockstep with one barrier per phase (profiles/r03_gemm_v3_phased.md): the second barrier costs more than the overlap returns.
+template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false, int ABL = 0, bool STAG = (ABL == 3)>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
 __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm_t p, const int splits, const int tiles_mn) {
     static_assert(WM * WN == 8, "two groups of four waves");
     static_assert(!std::is_same<T, float>::value, "v3 serves the 16-bit MFMA forms (bf16, f16, bf16x3)");
@@ -71,7 +79,8 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     constexpr int PA0 = (RA0 + 63) / 64, PA1 = (RA1 + 63) / 64, PB0 = (RB0 + 63) / 64, PB1 = (RB1 + 63) / 64;   // 64-row staging passes
     // pieces EVERY wave issues per slab (ragged last passes are issued by the first waves only): the counted wait. A wave that
     // issued more has more than NWAIT younger pieces outstanding, for which vmcnt(NWAIT) is the stricter wait.
-    constexpr int NWAIT = RA0 / 64 + RA1 / 64 + RB0 / 64 + RB1 / 64;
+    constexpr int CA0 = RA0 / 64, CA1 = RA1 / 64, CB0 = RB0 / 64, CB1 = RB1 / 64;
+    constexpr int NWAIT = CA0 + CA1 + CB0 + CB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     const long total = (long)tiles_mn * p.batch * splits;
     const long G = gridDim.x;
     const bool direct_rows = ntap == 1 && p.stride == 1 && p.ups == 1 && p.ph == 0 && p.pw == 0 && p.pt == 0 && p.Hin * p.Win == hw;
-    const int ns = p.K / BK / splits;                  // slabs per tile: the host guarantees an even split and ns >= 2
+    const int ns = p.K / BK / splits;                  // slabs per tile: the host guarantees an even split, ns even and >= 4
     const int ccol = tid & 7;
     const int r0 = tid >> 3;
 
@@ -236,9 +245,11 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(base + j * 64 * PITCH), 16, (int)voffB[H][j], (int)soffB, 0, 0);
         }
     };
-    // after B1 of slab t + 1: the B cursor moves to slab t + 2, which opens the next tile when t + 2 == ns
-    auto advance_B = [&](int t) {
-        if (t + 2 == ns) {
+    // after both B half panels of a slab went out: the B cursor moves on; past the tile's last slab it opens the next tile
+    int sA = 0, sB = 0;                                // slab of the A / B cursor inside its tile
+    auto advance_B = [&]() {
+        if (++sB == ns) {
+            sB = 0;
             stage_tile(wS + G);
             tapB = tap_beg;
             c0B = c0_beg;
@@ -247,9 +258,10 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             step_B();
         }
     };
-    // after A1 of slab t + 1: the same for the A cursor
-    auto advance_A = [&](int t) {
-        if (t + 2 == ns) {
+    // the same for the A cursor, which follows the B cursor by a phase or more (B runs three slabs ahead of the MFMAs, A two)
+    auto advance_A = [&]() {
+        if (++sA == ns) {
+            sA = 0;
             window_A(validS, tmS, bzS);
             begin_A();
         } else {
@@ -270,15 +282,15 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         foff[1] = lr * PITCH + (((4 + lq) ^ fkey) << 4);
     }
     const bool a_split = HOT ? (HOT == 2) : (p.a_split != 0), w_split = HOT ? true : (p.w_split != 0);
-    u32x4 fa[DA ? 2 : 1][2][MB0];                      // A fragments [half (one shared set without DA)][bf16x3: hi | lo; 16-bit: K half][block]
-    u32x4 fb[2][2][NB0];                               // both B halves (C0 is used again by the slab's last phase)
+    u32x4 fa[2][2][MB0];                               // A fragments [half][bf16x3: hi | lo; 16-bit: K half][block]: every half panel has its own
+    u32x4 fb[2][2][NB0];                               // registers, so that a phase can read the set the NEXT phase multiplies
     auto read_A = [&](auto hc, const char* sb) {
         constexpr int H = decltype(hc)::value;
         const char* base = sb + (H ? OA1 : OA0) + wr * ((H ? MB1 : MB0) * 16) * PITCH;
 #pragma unroll
         for (int a = 0; a < (H ? MB1 : MB0); ++a) {
-            fa[DA ? H : 0][0][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[0]);
-            fa[DA ? H : 0][1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);
+            fa[H][0][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[0]);
+            fa[H][1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);
         }
     };
     auto read_B = [&](auto hc, const char* sb) {
@@ -297,8 +309,8 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             if (!a_split) {
 #pragma unroll
                 for (int a = 0; a < (H ? MB1 : MB0); ++a) {
-                    const u32x4 x0 = fa[DA ? H : 0][0][a], x1 = fa[DA ? H : 0][1][a];
-                    split8_bf16(x0, x1, fa[DA ? H : 0][0][a], fa[DA ? H : 0][1][a]);
+                    const u32x4 x0 = fa[H][0][a], x1 = fa[H][1][a];
+                    split8_bf16(x0, x1, fa[H][0][a], fa[H][1][a]);
                 }
             }
         }
@@ -322,14 +334,14 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         constexpr int MBH = HA ? MB1 : MB0, NBH = HB ? NB1 : NB0, AO = HA ? MB0 : 0, BO = HB ? NB0 : 0;
         if constexpr (ABL == 2) {                       // keep the fragments live, skip the matrix pipe
 #pragma unroll
-            for (int a = 0; a < MBH; ++a) asm volatile("" ::"v"(fa[DA ? HA : 0][0][a]), "v"(fa[DA ? HA : 0][1][a]));
+            for (int a = 0; a < MBH; ++a) asm volatile("" ::"v"(fa[HA][0][a]), "v"(fa[HA][1][a]));
 #pragma unroll
             for (int b = 0; b < NBH; ++b) asm volatile("" ::"v"(fb[HB][0][b]), "v"(fb[HB][1][b]));
             return;
         }
         if constexpr (ABL == 5) {                       // stale fragments: keep the registers opaque
 #pragma unroll
-            for (int a = 0; a < MBH; ++a) asm volatile("" : "+v"(fa[DA ? HA : 0][0][a]), "+v"(fa[DA ? HA : 0][1][a]));
+            for (int a = 0; a < MBH; ++a) asm volatile("" : "+v"(fa[HA][0][a]), "+v"(fa[HA][1][a]));
 #pragma unroll
             for (int b = 0; b < NBH; ++b) asm volatile("" : "+v"(fb[HB][0][b]), "+v"(fb[HB][1][b]));
         }
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
                     for (int a = 0; a < MBH; ++a) {
                         const u32x4& wv = fb[HB][term == 0 ? 1 : 0][b];
-                        const u32x4& av = fa[DA ? HA : 0][term == 1 ? 1 : 0][a];
+                        const u32x4& av = fa[HA][term == 1 ? 1 : 0][a];
                         acc[AO + a][BO + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, av),
                                                                                       acc[AO + a][BO + b], 0, 0, 0);
                     }
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
                 for (int b = 0; b < NBH; ++b) {
 #pragma unroll
-                    for (int a = 0; a < MBH; ++a) mma16<T>(acc[AO + a][BO + b], fb[HB][h][b], fa[DA ? HA : 0][h][a]);
+                    for (int a = 0; a < MBH; ++a) mma16<T>(acc[AO + a][BO + b], fb[HB][h][b], fa[HA][h][a]);
                 }
             }
         }
@@ -374,7 +386,8 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         }
     };
 
-    // ---- first tile: windows, then the steady state's in-flight set A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) --------------------------------
+    // ---- first tile: windows, then the steady state's in-flight set A0(0) B0(0) B1(0) A1(0) A0(1) B1(1) B0(1) and the fragments of
+    // the first quadrant ----------------------------------------------------------------------------------------------------------------
     const long w0 = xcd_remap((long)blockIdx.x, G);    // each XCD walks a contiguous range of every round of G tiles
     if (w0 >= total) return;
     stage_tile(w0);
@@ -386,88 +399,87 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     issue_A(H0{}, 0);
     issue_B(H0{}, 0);
     issue_B(H1{}, 0);
-    step_B();
+    advance_B();
     issue_A(H1{}, 0);
-    step_A();
+    advance_A();
     issue_A(H0{}, 1);
+    issue_B(H1{}, 1);
     issue_B(H0{}, 1);
+    advance_B();
     int tmC = tmS, tnC = tnS, kzC = kzS;               // the tile the MFMAs are in
     long bzC = bzS;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");   // A0(0) B0(0) B1(0) landed; A1(0) A0(1) B1(1) B0(1) may be in flight
     __syncthreads();
-    if constexpr (DA) read_A(H0{}, smem);              // A0 fragments of slab 0 (afterwards phase 3 reads the next slab's)
-    if (grp == 1 && ABL != 3) GEO4D_V3_BAR();
+    read_A(H0{}, smem);
+    read_B(H0{}, smem);
+    if (grp == 1 && STAG) GEO4D_V3_BAR();
 
-    int g = 0;                                         // ring stage of the current slab (slabs are counted across tiles)
     while (true) {
 #pragma unroll
         for (int a = 0; a < MB; ++a)
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < ns; ++t, g ^= 1) {
-            const char* sb = smem + g * STAGE;
-            // Every phase: [issue one half panel of a future slab | read the fragments this or the next phase needs | counted wait]
-            // barrier [quadrant MFMAs | cursor / pointer work for the NEXT phase's issue] barrier. The wait of phase k retires the half
-            // panel whose fragments are read in phase k + 1 (A0 of slab t + 1 in phase 2 when DA reads it in phase 3).
-            // phase 0: quadrant (R0, C0) | B1 of slab t + 1
-            stamp(t, 0);
-            if constexpr (ABL != 1) issue_B(H1{}, g ^ 1);
-            if constexpr (ABL != 5) {
-                if constexpr (!DA) read_A(H0{}, sb);
-                read_B(H0{}, sb);
-            }
-            GEO4D_V3_WAIT();
-            stamp(t, 1);
+        // One slab = four phases, one per quadrant of the wave tile; the quadrants are walked so that consecutive phases share one
+        // operand half, and the half the NEXT phase needs is read while this phase's MFMAs run (its registers are free by construction):
+        //   slab parity 0: (A0,B0) (A0,B1) (A1,B1) (A1,B0)      parity 1: (A0,B1) (A0,B0) (A1,B0) (A1,B1)      [X = parity, Y = 1 - X]
+        //   phase 0: issue A1 of slab c + 1 (other ring stage) | read B_Y of slab c      | MFMA (A0, B_X)
+        //   phase 1: issue A0 of slab c + 2                    | read A1 of slab c       | MFMA (A0, B_Y)
+        //   phase 2: issue B_X of slab c + 2                   | read A0 of slab c + 1   | MFMA (A1, B_Y)
+        //   phase 3: issue B_Y of slab c + 2                   | read B_Y of slab c + 1  | MFMA (A1, B_X)
+        // Half panels are issued in the order they are read, FIVE phases ahead, and re-staged three phases after their read. The wait of
+        // a phase retires the half panel the next phase reads: everything but the four half panels issued after it.
+        auto slab = [&](auto xc, int t) __attribute__((always_inline)) {
+            constexpr int X = decltype(xc)::value, Y = 1 - X;
+            using HX = std::integral_constant<int, X>;
+            using HY = std::integral_constant<int, Y>;
+            const char* sb = smem + X * STAGE;           // slabs of parity X live in ring stage X: tiles are whole pairs of slabs
+            const char* so = smem + Y * STAGE;
+            auto phase = [&](auto jc, auto issue, auto read, auto split, auto mma, auto after) __attribute__((always_inline)) {
+                constexpr int J = decltype(jc)::value;
+                constexpr int NW = J == 2 ? 2 * (X ? CB1 : CB0) + CA1 + CA0 : NWAIT;
+                stamp(t, 4 * J);
+                if constexpr (ABL != 1) issue();
+                if constexpr (ABL != 5) read();
+                if constexpr (STAG) {
+                    if constexpr (ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+                    stamp(t, 4 * J + 1);
+                    GEO4D_V3_LBAR();
+                }
+                stamp(t, 4 * J + 2);
+                split();
+                mma();
+                after();
+                if constexpr (!STAG && ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+                stamp(t, 4 * J + 3);
+            };
+            phase(std::integral_constant<int, 0>{}, [&] { issue_A(H1{}, Y); }, [&] { read_B(HY{}, sb); },
+                  [&] { split_A(H0{}); split_B(HX{}); }, [&] { mma_quadrant(H0{}, HX{}); }, [&] { advance_A(); });
             GEO4D_V3_LBAR();
-            stamp(t, 2);
-            split_A(H0{});
-            split_B(H0{});
-            mma_quadrant(H0{}, H0{});
-            if (ABL != 4 || t + 2 == ns) advance_B(t);
-            stamp(t, 3);
+            phase(std::integral_constant<int, 1>{}, [&] { issue_A(H0{}, X); }, [&] { read_A(H1{}, sb); },
+                  [&] { split_B(HY{}); }, [&] { mma_quadrant(H0{}, HY{}); }, [&] {});
             GEO4D_V3_LBAR();
-            // phase 1: quadrant (R0, C1) | A1 of slab t + 1
-            stamp(t, 4);
-            if constexpr (ABL != 1) issue_A(H1{}, g ^ 1);
-            if constexpr (ABL != 5) read_B(H1{}, sb);
-            GEO4D_V3_WAIT();
-            stamp(t, 5);
+            phase(std::integral_constant<int, 2>{}, [&] { issue_B(HX{}, X); }, [&] { read_A(H0{}, so); },
+                  [&] { split_A(H1{}); }, [&] { mma_quadrant(H1{}, HY{}); }, [&] {});
             GEO4D_V3_LBAR();
-            stamp(t, 6);
-            split_B(H1{});
-            mma_quadrant(H0{}, H1{});
-            if (ABL != 4 || t + 2 == ns) advance_A(t);
-            stamp(t, 7);
+            phase(std::integral_constant<int, 3>{}, [&] { issue_B(HY{}, X); }, [&] { read_B(HY{}, so); },
+                  [&] {}, [&] { mma_quadrant(H1{}, HX{}); }, [&] { advance_B(); });
+        };
+        for (int t = 0; t < ns; t += 2) {
+            slab(H0{}, t);
             GEO4D_V3_LBAR();
-            // phase 2: quadrant (R1, C1) | A0 of slab t + 2
-            stamp(t, 8);
-            if constexpr (ABL != 1) issue_A(H0{}, g);
-            if constexpr (ABL != 5) read_A(H1{}, sb);
-            GEO4D_V3_WAIT();
-            stamp(t, 9);
-            GEO4D_V3_LBAR();
-            stamp(t, 10);
-            split_A(H1{});
-            mma_quadrant(H1{}, H1{});
-            stamp(t, 11);
-            GEO4D_V3_LBAR();
-            // phase 3: quadrant (R1, C0) | B0 of slab t + 2 | with DA: the A0 fragments of slab t + 1 (other ring stage)
-            stamp(t, 12);
-            if constexpr (ABL != 1) issue_B(H0{}, g);
-            if constexpr (ABL != 5 && DA) read_A(H0{}, smem + (g ^ 1) * STAGE);
-            GEO4D_V3_WAIT();
-            stamp(t, 13);
-            GEO4D_V3_LBAR();
-            stamp(t, 14);
-            mma_quadrant(H1{}, H0{});
-            stamp(t, 15);
-            if (t + 1 < ns) GEO4D_V3_LBAR();
+            slab(H1{}, t + 1);
+            if (t + 2 < ns) GEO4D_V3_LBAR();
         }
         // the tile's closing barrier, then the epilogue (group 1's runs beside group 0's next fragment reads / DMA issue).
         // (Putting group 1's epilogue BEFORE the barrier so that both share one interval makes the register allocator spill ~900
         // VGPRs, including reloads inside the K loop whose vmcnt(0) drain the DMA queue - measured on the ISA, not worth it.)
         GEO4D_V3_BAR();
-        reg_epilogue<MB, NB, OSPLIT, true>(p, acc, tmC * BM + wr * WTM, tnC * BN + wc * WTN, bzC, kzC, partial, lr, lq);
+        {   // the lane's row / column indices go through an opaque copy: otherwise the tile-invariant parts of the epilogue's addresses
+            // (dozens of 64-bit row offsets) are hoisted out of the tile loop and live - spilled - across the K loop
+            int lr_ = lr, lq_ = lq;
+            asm volatile("" : "+v"(lr_), "+v"(lq_));
+            reg_epilogue<MB, NB, OSPLIT, true>(p, acc, tmC * BM + wr * WTM, tnC * BN + wc * WTN, bzC, kzC, partial, lr_, lq_);
+        }
         // a REAL s_waitcnt vmcnt(0) (the builtin, which the compiler's wait-count pass tracks; an inline-asm one it does not see):
         // without it the pass has to assume pending loads into VGPRs at the K loop's header and drains the DMA queue every slab
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         if (!validS) break;                            // the staging tile is the next tile of the MFMAs
         tmC = tmS; tnC = tnS; kzC = kzS; bzC = bzS;
     }
-    if (grp == 0 && ABL != 3) GEO4D_V3_BAR();
+    if (grp == 0 && STAG) GEO4D_V3_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy pieces of the stream's tail must land before the LDS is released
     if constexpr (ABL == 8) {
         __syncthreads();
@@ -539,8 +551,9 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 }
 
 // tile hints 71..74: phased K loop on 8 waves (2 x 4), one workgroup per CU
-//   71: 256x256 (wave tiles 128x64)   72: 160x320 (80x80)   73: 256x128 (128x32)   74: 128x256 (64x64)
-// Launches the phased stream cannot take (fewer than 2 slabs per tile, an uneven split-K, outputs that are not 4-element aligned,
+//   71: 192x256 (wave tiles 96x64)   72: 160x320 (80x80)   73: 256x128 (128x32)   74: 128x256 (64x64)
+// (256x256 does not fit: 128 accumulators + the four fragment sets of the prefetching walk spill)
+// Launches the phased stream cannot take (an odd number or fewer than 4 K slabs per tile, an uneven split-K, outputs that are not 4-element aligned,
 // nearest-upsampling gathers, operands beyond the 2 GB buffer window) fall back to the second-generation tile of the same shape.
 template <typename T>
 int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
@@ -561,20 +574,19 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             }
             sp = p.split_k;
         }
-#ifdef GEO4D_GEMM_ABLATION   // profiling build (make ABLATION=1): 80 + a = 160x320, 90 + a = 256x256 with ablation a, pre-split x pre-split bf16x3 only
+#ifdef GEO4D_GEMM_ABLATION   // profiling build (make ABLATION=1): 80 + a = 160x320, 90 + a = 192x256 with ablation a, pre-split x pre-split bf16x3 only
         if constexpr (IsX3<T>::value) {
             if (p.w_split && p.a_split && !p.o_split) switch (p.tile_hint) {
 #define GEO4D_ABL3(base, BM_, BN_)                                                                        \
                 case base + 1: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 1>(p, sp, stream); \
                 case base + 2: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 2>(p, sp, stream); \
                 case base + 3: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 3>(p, sp, stream); \
-                case base + 4: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 4>(p, sp, stream); \
                 case base + 5: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 5>(p, sp, stream); \
                 case base + 6: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 6>(p, sp, stream); \
                 case base + 7: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 7>(p, sp, stream); \
                 case base + 8: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 8>(p, sp, stream);
                 GEO4D_ABL3(80, 160, 320)
-                GEO4D_ABL3(90, 256, 256)
+                GEO4D_ABL3(90, 192, 256)
 #undef GEO4D_ABL3
             }
         }
@@ -599,13 +611,13 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
         const long esz = 16 / Elem<T>::EPC;
         const long frames = 256 / ((long)p.Hout * p.Wout) + 2 + p.KT;
         const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
-        if (nslab % sp || nslab / sp < 2 || !vec_ok || !window_ok) {
+        if (nslab % sp || ((nslab / sp) & 1) || nslab / sp < 4 || !vec_ok || !window_ok) {
             geo4d_conv_gemm_t q = p;
             q.tile_hint = p.tile_hint == 71 ? 22 : p.tile_hint == 72 ? 23 : p.tile_hint == 73 ? 21 : 29;
             return launch_v2_typed<T>(q, stream);
         }
         switch (p.tile_hint) {
-            case 71: return launch_v3_cfg<T, 256, 256, 2, 4>(p, sp, stream);
+            case 71: return launch_v3_cfg<T, 192, 256, 2, 4>(p, sp, stream);
             case 72: return launch_v3_cfg<T, 160, 320, 2, 4>(p, sp, stream);
             case 73: return launch_v3_cfg<T, 256, 128, 2, 4>(p, sp, stream);
             case 74: return launch_v3_cfg<T, 128, 256, 2, 4>(p, sp, stream);

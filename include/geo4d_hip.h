@@ -67,8 +67,8 @@ typedef struct geo4d_conv_gemm_t {
                             buffers (the A panel two K slabs ahead): 31 = 256x128, 33 = 160x320, 34 = 160x160, 35 = 128x128,
                             39 = 128x256; GEGLU on 21, 22, 25, 27, 29, 31, 35, 39. The same MFMA form and epilogue under a PHASED
                             K loop (4 phases per slab, counted LDS-DMA waits, two staggered wave groups, the staging cursor
-                            two slabs ahead across tiles; 8 waves, one workgroup per CU): 71 = 256x256, 72 = 160x320,
-                            73 = 256x128, 74 = 128x256; GEGLU on 71, 74; launches with fewer than 2 slabs per tile, an uneven
+                            two slabs ahead across tiles; 8 waves, one workgroup per CU): 71 = 192x256, 72 = 160x320,
+                            73 = 256x128, 74 = 128x256; GEGLU on 71, 74; launches with an odd number or fewer than 4 K slabs per tile, an uneven
                             split-K or outputs that are not 4-element aligned run on 22 / 23 / 21 / 29 instead.
                             Others: -EINVAL */
     int split_k;         /* 0 auto (powers of two), 1 never, n >= 2: n-way split (needs workspace; tile hints >= 21 take any n) */

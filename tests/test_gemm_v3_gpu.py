@@ -17,7 +17,7 @@ from test_gemm_v2_gpu import MODES, TOL, act_dtype, both_grids, check, pack_mode
 
 pytestmark = pytest.mark.gpu
 
-V3_TILES = [71, 72, 73, 74]      # 256x256, 160x320, 256x128, 128x256 on 2 x 4 waves
+V3_TILES = [71, 72, 73, 74]      # 192x256, 160x320, 256x128, 128x256 on 2 x 4 waves
 GEGLU_TILES = {71, 74}           # wave tiles a multiple of 64 columns wide
 
 
@@ -30,7 +30,7 @@ def same_as_v2(name, got, fn_v2):
 @pytest.mark.parametrize("tile", V3_TILES)
 def test_linear_bias_residual_ragged(dev, mode, tile):
     from geo4d_amd import ops, pack
-    M, K, N = 1000, 320, 456          # ragged in M and N for every tile; several tiles per workgroup under debug_ablate = 2
+    M, K, N = 1000, 512, 456          # ragged in M and N for every tile; several tiles per workgroup under debug_ablate = 2; 8 / 16 K slabs
     x, w = rnd((M, K), dev, 1).to(act_dtype(mode)), rnd((N, K), dev, 2, 0.05)
     b, r = rnd((N,), dev, 3), rnd((M, N), dev, 4).to(act_dtype(mode))
     wp = pack.pack_linear(w, pack_mode(mode))
@@ -106,11 +106,11 @@ def test_temporal_conv(dev, mode, tile):
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("tile", [71, 72])
 def test_launches_the_phased_stream_cannot_take_fall_back(dev, mode, tile):
-    """One K slab per tile (K = 32 f32 / 64 16-bit elements), an uneven split-K, an unaligned output pitch: the library routes these to
-    the second-generation tile of the same shape instead of refusing."""
+    """One K slab per tile (K = 32 f32 / 64 16-bit elements), an odd slab count, an uneven split-K, an unaligned output pitch: the library
+    routes these to the second-generation tile of the same shape instead of refusing."""
     from geo4d_amd import ops, pack
     M = 333
-    for K, N, split in ((64 if mode != "bf16x3" else 32, 128, 1), (448, 128, 4), (128, 77, 1)):
+    for K, N, split in ((64 if mode != "bf16x3" else 32, 128, 1), (320 if mode != "bf16x3" else 160, 128, 1), (448, 128, 4), (128, 77, 1)):
         x, w, b = rnd((M, K), dev, 30).to(act_dtype(mode)), rnd((N, K), dev, 31, 0.1), rnd((N,), dev, 32)
         r = rnd((M, N), dev, 33).to(act_dtype(mode))
         out = both_grids(lambda: ops.linear(x, pack.pack_linear(w, pack_mode(mode)), b, residual=r, tile_hint=tile, split_k=split))

@@ -22,7 +22,7 @@ def main():
         b = torch.randn((N,), device=dev)
         xa = ops.SplitAct.wrap(pack.split_bf16(x))
         run = lambda t: ops.conv2d(xa, w, b, F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, tile_hint=t, split_k=1)[0]
-    else:                        # L2 ffout 5120 -> 1280 (plain linear, K = 5120) on the 256x256 tile
+    else:                        # L2 ffout 5120 -> 1280 (plain linear, K = 5120) on the 192x256 tile
         M, K, N, tile = 2560, 5120, 1280, 98
         x = torch.randn((M, K), device=dev)
         w = pack.split_bf16(torch.randn((N, K), device=dev) / K ** 0.5)
