@@ -181,3 +181,22 @@ def test_presplit_operands_and_split_output(dev):
         assert torch.equal(hi, plain.to(torch.bfloat16).float()) and ((hi + lo - plain).norm() / plain.norm()).item() < 2e-5, tile
         assert torch.equal(split, ops.linear(make_split(x), wgp, bgp, act=2, tile_hint=22, split_out=True).as_subclass(torch.Tensor)), tile
         assert math.isfinite(plain.sum().item())
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_batched_gemm_alpha(dev, mode):
+    """Batched GEMM with both operands raw (the VAE AttnBlock's Q.K^T form; bf16x3 splits both fragments in registers): batch strides,
+    alpha, the workgroups' tile stream crossing batch boundaries."""
+    from geo4d_amd import ops
+    Bz, M, N, K = 3, 200, 136, 256
+    a, bt = rnd((Bz, M, K), dev, 60).to(act_dtype(mode)), rnd((Bz, N, K), dev, 61).to(act_dtype(mode))
+
+    def run(tile):
+        out = torch.empty((Bz, M, N), device=dev, dtype=act_dtype(mode))
+        ops.conv_gemm(a, bt, out, M=M, N=N, K=K, Cin=K, lda=K, ldw=K, ldo=N, batch=Bz, a_bs=M * K, w_bs=N * K, o_bs=M * N, alpha=0.25,
+                      tile_hint=tile, x3=(mode == "bf16x3"))
+        return out
+    ref = run(25)
+    check("batched v2", ref, 0.25 * a.float() @ bt.float().transpose(1, 2), mode)
+    for tile in V3_TILES:
+        assert torch.equal(both_grids(lambda: run(tile)), ref), f"tile {tile}"
