@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
     ap.add_argument("--explore2", action="store_true", help="per shape: best 32x32-MFMA configuration (tile hints 1..17) vs best second-generation one (21..29), and every 21..29 tile at split 1")
     ap.add_argument("--tiles", default="", help="comma list of tile hints to time per shape (split 1), e.g. the ablation builds 40..64")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands: same instruction stream, no data toggling (how much of the time is the chip's power-limited clock?)")
     ap.add_argument("--presplit", action="store_true", help="bf16x3: hand the activation over in the producers' pre-split format (what the networks run)")
     ap.add_argument("--ablate", type=int, default=0, help="bf16x3 only: 1 = skip the in-register operand split (wrong numbers; measures its cost)")
     args = ap.parse_args()
@@ -69,6 +70,8 @@ def main():
     wcast = (lambda w: pack.split_bf16(w)) if x3 else (lambda w: w.to(dt))
     acast = (lambda a: ops.SplitAct.wrap(pack.split_bf16(a))) if (x3 and args.presplit) else (lambda a: a)
     dev = torch.device("cuda:0")
+    if args.zeros:
+        torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "generator"})
     tot_ms, tot_tf = 0.0, 0.0
     print(f"{'shape':34s} {'M':>8s} {'N':>6s} {'K':>6s} {'us':>9s} {'TF/s':>8s}  x count -> ms/forward")
     for name, kind, geo, N, Cin, cnt in SHAPES:
