@@ -57,12 +57,13 @@ constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH; }
         if constexpr (ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");   \
     } while (0)
 
-// ABL (profiling builds only, tile hints 80..99, WRONG results by construction except 3 and 8): 1 = no LDS-DMA inside the K loop, 2 = no MFMA, 3 =// 
-// STAGGERED wave groups (see STAG), 4 = unused, 5 = no fragment reads, 6 = no DMA waits, 7 = no barriers;
-// 8 = CORRECT results plus s_memtime stamps of waves 0 and 4 of workgroup 0 (4 per phase, slabs 8..23 of its first tile) -> p.workspace
-// STAG (ablation 3 only): the two wave groups run staggered by one barrier, with a second barrier inside every phase (issue / read |
-// MFMA), so that one group's MFMA segment runs beside the other group's issue segment. Measured 4-10 % SLOWER than all eight waves in
-// lockstep with one barrier per phase (profiles/r03_gemm_v3_phased.md): the second barrier costs more than the overlap returns.
+// ABL (profiling builds only: make ABLATION=1, tile hints 80 + a / 90 + a; WRONG results by construction except 3 and 8):
+//   1 = no LDS-DMA inside the K loop   2 = no MFMA   3 = staggered wave groups (see STAG)   5 = no fragment reads   6 = no DMA waits
+//   7 = no barriers   8 = s_memtime stamps of waves 0 and 4 of workgroup 0 (4 per phase, slabs 8..23 of its first tile) -> p.workspace
+// STAG (ablation 3 only): the two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run staggered by one barrier, with a second
+// barrier inside every phase (issue / read | MFMA), so that one group's MFMA segment runs beside the other group's issue segment.
+// Measured 4-10 % SLOWER than all eight waves in lockstep with one barrier per phase (profiles/r03_gemm_v3_phased.md): the second
+// barrier costs more than the overlap returns.
 template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false, int ABL = 0, bool STAG = (ABL == 3)>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
 __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm_t p, const int splits, const int tiles_mn) {
     static_assert(WM * WN == 8, "two groups of four waves");
@@ -470,9 +471,9 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             slab(H1{}, t + 1);
             if (t + 2 < ns) GEO4D_V3_LBAR();
         }
-        // the tile's closing barrier, then the epilogue (group 1's runs beside group 0's next fragment reads / DMA issue).
-        // (Putting group 1's epilogue BEFORE the barrier so that both share one interval makes the register allocator spill ~900
-        // VGPRs, including reloads inside the K loop whose vmcnt(0) drain the DMA queue - measured on the ISA, not worth it.)
+        // the tile's closing barrier, then the epilogue; the next tile's first slabs are already in flight. (An epilogue placed on either
+        // side of the barrier depending on the wave group made the register allocator spill ~900 VGPRs, with reloads - and their
+        // vmcnt(0) - inside the K loop.)
         GEO4D_V3_BAR();
         {   // the lane's row / column indices go through an opaque copy: otherwise the tile-invariant parts of the epilogue's addresses
             // (dozens of 64-bit row offsets) are hoisted out of the tile loop and live - spilled - across the K loop

@@ -1,10 +1,10 @@
 """Third-generation conv_gemm kernel (tile hints 71..74: the second generation's MFMA form, LDS image and register epilogue under a
-phased K loop with counted DMA waits on two staggered wave groups; geo4d_amd/csrc/gemm_kernel_v3.h) through the C ABI.
+phased, software-pipelined K loop with counted DMA waits and buffer-resource staging; geo4d_amd/csrc/gemm_kernel_v3.h) through the C ABI.
 
 The K order and the per-accumulator summation order are those of the second generation, so every case is checked TWICE: against plain
 PyTorch fp32 math, and bit for bit against a second-generation tile (hint 25) on the same operands. Each case also runs with
-`debug_ablate = 2` (3 persistent workgroups: the staging cursor crosses tile boundaries - the next tile's gather table, weight rows and
-first two slabs are issued inside the current tile's last two slabs - on small shapes). The races this schedule could have (a fragment
+`debug_ablate = 2` (3 persistent workgroups: the staging cursors cross tile boundaries - the next tile's buffer windows and first slabs
+are issued inside the current tile's last slabs - on small shapes). The races this schedule could have (a fragment
 read before its half panel landed, a half panel re-staged under a late reader) do not show as a fixed wrong answer, so the full-chip
 case repeats launches and compares them bit for bit."""
 import math
