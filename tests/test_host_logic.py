@@ -277,3 +277,37 @@ def test_reference_checkpoint_loads_the_lazily_built_encoders():
     assert "cond_stage_model" not in late.__dict__["_frontend_unloaded"] and "_geo4d_context_cache" not in late.__dict__
     foreign = _tiny_lvd(frontend=False)
     assert not hasattr(foreign, "cond_stage_model") and not hasattr(foreign, "embedder")
+
+
+def test_third_generation_tile_hints_validate_on_the_host():
+    """Tile hints 71..74 (gemm_kernel_v3.h): what they cannot serve is refused with -EINVAL and a message before any launch (the
+    descriptor's pointers are never dereferenced on the host), and unknown hints next to them stay unknown."""
+    from geo4d_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_char * 4096)()
+    addr = ctypes.addressof(buf)
+
+    def desc(dtype, tile, **kw):
+        p = _lib.ConvGemm()
+        p.A = p.W = p.O = p.zeros = p.workspace = addr
+        p.workspace_bytes = 4096
+        p.M, p.N, p.K, p.Cin, p.batch = 256, 256, 512, 512, 1
+        p.lda = p.ldw = 512
+        p.ldo = 256
+        p.T = p.Hin = p.Win = p.Hout = p.Wout = p.KT = p.KH = p.KW = p.stride = p.ups = 1
+        p.Hin = p.Hout = 256                      # 256 "pixels" of one frame: M = T * Hout * Wout
+        p.dtype = p.out_dtype = dtype
+        p.alpha = 1.0
+        p.tile_hint = tile
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+    F32, BF16 = 0, 1
+    for tile in (71, 72, 73, 74):
+        assert lib.geo4d_conv_gemm(ctypes.byref(desc(F32, tile)), None) == -22
+        assert b"71..74" in lib.geo4d_last_error(), lib.geo4d_last_error()
+        assert lib.geo4d_conv_gemm(ctypes.byref(desc(BF16, tile, out_nchw=1, ldo=256)), None) == -22
+        assert b"NCTHW" in lib.geo4d_last_error(), lib.geo4d_last_error()
+    for tile in (70, 75, 79):
+        assert lib.geo4d_conv_gemm(ctypes.byref(desc(BF16, tile)), None) == -22
+        assert b"tile_hint" in lib.geo4d_last_error(), lib.geo4d_last_error()
