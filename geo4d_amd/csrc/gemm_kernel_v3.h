@@ -58,7 +58,9 @@ constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH; }
     } while (0)
 
 // ABL (profiling builds only: make ABLATION=1, tile hints 80 + a / 90 + a; WRONG results by construction except 3 and 8):
-//   1 = no LDS-DMA inside the K loop   2 = no MFMA   3 = staggered wave groups (see STAG)   5 = no fragment reads   6 = no DMA waits
+//   1 = no LDS-DMA inside the K loop   2 = no MFMA   3 = staggered wave groups (see STAG)   4 = WITH s_setprio around the MFMAs (correct results;
+//   the shipped lockstep kernel has none: -1..-4 % with it)
+//   5 = no fragment reads   6 = no DMA waits   9 = waves 4-7 issue their DMA pieces after the first third of the quadrant's MFMAs (correct results)
 //   7 = no barriers   8 = s_memtime stamps of waves 0 and 4 of workgroup 0 (4 per phase, slabs 8..23 of its first tile) -> p.workspace
 // STAG (ablation 3 only): the two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run staggered by one barrier, with a second
 // barrier inside every phase (issue / read | MFMA), so that one group's MFMA segment runs beside the other group's issue segment.
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     };
     // quadrant (HA, HB): term-major so that consecutive MFMAs write different accumulators; per accumulator the terms keep the order
     // of mma16_x3 (w.lo x a.hi, w.hi x a.lo, w.hi x a.hi; C rows = n, C cols = m) resp. K half 0, 1
-    auto mma_quadrant = [&](auto hac, auto hbc) {
+    auto mma_quadrant = [&](auto hac, auto hbc, auto mid) {
         constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
         constexpr int MBH = HA ? MB1 : MB0, NBH = HB ? NB1 : NB0, AO = HA ? MB0 : 0, BO = HB ? NB0 : 0;
         if constexpr (ABL == 2) {                       // keep the fragments live, skip the matrix pipe
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
             for (int b = 0; b < NBH; ++b) asm volatile("" : "+v"(fb[HB][0][b]), "+v"(fb[HB][1][b]));
         }
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (STAG || ABL == 4) __builtin_amdgcn_s_setprio(1);     // only the staggered schedule has something to arbitrate
         if constexpr (IsX3<T>::value) {
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
                                                                                       acc[AO + a][BO + b], 0, 0, 0);
                     }
                 }
+                if (term == 0) mid();
             }
         } else {
 #pragma unroll
@@ -369,9 +372,10 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
                     for (int a = 0; a < MBH; ++a) mma16<T>(acc[AO + a][BO + b], fb[HB][h][b], fa[HA][h][a]);
                 }
+                if (h == 0) mid();
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (STAG || ABL == 4) __builtin_amdgcn_s_setprio(0);
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
                 constexpr int J = decltype(jc)::value;
                 constexpr int NW = J == 2 ? 2 * (X ? CB1 : CB0) + CA1 + CA0 : NWAIT;
                 stamp(t, 4 * J);
-                if constexpr (ABL != 1) issue();
+                if (ABL != 1 && (ABL != 9 || grp == 0)) issue();
                 if constexpr (ABL != 5) read();
                 if constexpr (STAG) {
                     if constexpr (ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
@@ -448,22 +452,22 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
                 }
                 stamp(t, 4 * J + 2);
                 split();
-                mma();
+                mma([&] { if (ABL == 9 && grp == 1) issue(); });
                 after();
                 if constexpr (!STAG && ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
                 stamp(t, 4 * J + 3);
             };
             phase(std::integral_constant<int, 0>{}, [&] { issue_A(H1{}, Y); }, [&] { read_B(HY{}, sb); },
-                  [&] { split_A(H0{}); split_B(HX{}); }, [&] { mma_quadrant(H0{}, HX{}); }, [&] { advance_A(); });
+                  [&] { split_A(H0{}); split_B(HX{}); }, [&](auto mid) { mma_quadrant(H0{}, HX{}, mid); }, [&] { advance_A(); });
             GEO4D_V3_LBAR();
             phase(std::integral_constant<int, 1>{}, [&] { issue_A(H0{}, X); }, [&] { read_A(H1{}, sb); },
-                  [&] { split_B(HY{}); }, [&] { mma_quadrant(H0{}, HY{}); }, [&] {});
+                  [&] { split_B(HY{}); }, [&](auto mid) { mma_quadrant(H0{}, HY{}, mid); }, [&] {});
             GEO4D_V3_LBAR();
             phase(std::integral_constant<int, 2>{}, [&] { issue_B(HX{}, X); }, [&] { read_A(H0{}, so); },
-                  [&] { split_A(H1{}); }, [&] { mma_quadrant(H1{}, HY{}); }, [&] {});
+                  [&] { split_A(H1{}); }, [&](auto mid) { mma_quadrant(H1{}, HY{}, mid); }, [&] {});
             GEO4D_V3_LBAR();
             phase(std::integral_constant<int, 3>{}, [&] { issue_B(HY{}, X); }, [&] { read_B(HY{}, so); },
-                  [&] {}, [&] { mma_quadrant(H1{}, HX{}); }, [&] { advance_B(); });
+                  [&] {}, [&](auto mid) { mma_quadrant(H1{}, HX{}, mid); }, [&] { advance_B(); });
         };
         for (int t = 0; t < ns; t += 2) {
             slab(H0{}, t);
@@ -582,7 +586,9 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
                 case base + 1: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 1>(p, sp, stream); \
                 case base + 2: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 2>(p, sp, stream); \
                 case base + 3: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 3>(p, sp, stream); \
+                case base + 4: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 4>(p, sp, stream); \
                 case base + 5: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 5>(p, sp, stream); \
+                case base + 9: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 9>(p, sp, stream); \
                 case base + 6: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 6>(p, sp, stream); \
                 case base + 7: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 7>(p, sp, stream); \
                 case base + 8: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 8>(p, sp, stream);
