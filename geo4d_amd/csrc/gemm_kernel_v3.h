@@ -128,11 +128,13 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     // A cursor: tap (kt, ky, kx) and channel slab -> SGPR byte offset + bit index of the tap; B cursor: the same for the weight's K axis
     int ktA = 0, kyA = 0, kxA = 0, c0A = 0, tapB = 0, c0B = 0, tap_beg = 0, c0_beg = 0;
     unsigned soffA = 0, bitA = 0, soffB = 0;
+    // (readfirstlane: the values are wave-uniform, but after a tile switch they come out of VALU code (integer divisions), and a buffer
+    // load whose SGPR offset operand sits in a VGPR is legalised with a waterfall loop around every piece)
     auto refresh_A = [&]() {
-        soffA = (unsigned)((((long)ktA * p.Hin + kyA) * p.Win + kxA) * p.lda + c0A) * ESZ;
-        bitA = (unsigned)((ktA * p.KH + kyA) * p.KW + kxA);
+        soffA = __builtin_amdgcn_readfirstlane((unsigned)((((long)ktA * p.Hin + kyA) * p.Win + kxA) * p.lda + c0A) * ESZ);
+        bitA = __builtin_amdgcn_readfirstlane((unsigned)((ktA * p.KH + kyA) * p.KW + kxA));
     };
-    auto refresh_B = [&]() { soffB = (unsigned)(tapB * p.Cin + c0B) * ESZ; };
+    auto refresh_B = [&]() { soffB = __builtin_amdgcn_readfirstlane((unsigned)(tapB * p.Cin + c0B) * ESZ); };
     auto begin_A = [&]() {                             // cursor at the tile's first slab
         ktA = tap_beg / khw;
         const int r2 = tap_beg - ktA * khw;

@@ -1,0 +1,58 @@
+"""Compiler-level guards for the phased conv_gemm K loop (geo4d_amd/csrc/gemm_kernel_v3.h), checked on the gfx950 ISA hipcc emits
+(cross-compiles without a GPU). The schedule only works if the compiler keeps three properties that it silently broke several times while
+the kernel was written (profiles/r03_gemm_v3_phased.md):
+  * no scratch: a spilled value is reloaded with a VMEM load, whose wait is an `s_waitcnt vmcnt(0)` in the middle of the loop;
+  * no `vmcnt(0)` between the first and the last MFMA of the kernel (the counted waits keep a slab of LDS-DMA in flight across barriers);
+  * the staging loads are `buffer_load_dwordx4 ... lds` on SGPR resources and SGPR offsets - no waterfall loop (`v_readfirstlane` + branch)
+    around them, which is what a resource or offset the compiler believes divergent turns into."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+CASES = [
+    ("160x320 split x split", "bf16x3_t, 160, 320, 2, 4, 2, false", 7),     # counted wait = pieces of one slab of this tile: 1 + 1 + 3 + 2
+    ("192x256 GEGLU writing the split format", "bf16x3_t, 192, 256, 2, 4, 2, true", 6),    # 1 + 1 + 2 + 2
+    ("128x256 bf16", "bf16_t, 128, 256, 2, 4, 0, false", 6),
+]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name,targs,nwait", CASES, ids=[c[0] for c in CASES])
+def test_phased_k_loop_keeps_its_pipeline(name, targs, nwait):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        src, asm = os.path.join(d, "k.hip"), os.path.join(d, "k.s")
+        with open(src, "w") as f:
+            f.write('#include "gemm_kernel_v3.h"\nnamespace geo4d_gemm {\n'
+                    f"template __global__ void conv_gemm_v3_kernel<{targs}>(const geo4d_conv_gemm_t, const int, const int);\n}}\n")
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/geo4d_amd/csrc",
+                            "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", "--cuda-device-only", "-S",
+                            "-Rpass-analysis=kernel-resource-usage", "-o", asm, src], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        usage = r.stderr
+        assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", usage), re.findall(r"(?:ScratchSize|VGPRs Spill)[^\n]*", usage)
+        vgprs = int(re.search(r"VGPRs: (\d+)", usage).group(1))
+        assert vgprs <= 256, vgprs                     # two waves per SIMD
+        lines = open(asm).read().splitlines()
+    mf = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32" in l]
+    assert len(mf) >= 8 * 4, len(mf)
+    loop = lines[mf[0]:mf[-1] + 1]
+    text = "\n".join(loop)
+    assert "scratch_" not in text
+    assert not re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", text), "a drained DMA queue inside the K loop"
+    counted = [int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)]
+    assert len(counted) >= 7 and nwait in counted and min(counted) >= nwait - 1, counted
+    loads = [i for i, l in enumerate(loop) if "buffer_load_dwordx4" in l and " lds" in l]
+    assert len(loads) >= 8, len(loads)
+    for i in loads:
+        assert re.search(r"buffer_load_dwordx4 v\d+, s\[\d+:\d+\], s\d+ offen lds", loop[i]), loop[i]
+        window = "\n".join(loop[max(0, i - 6):i + 4])
+        assert "v_readfirstlane" not in window and "s_and_saveexec" not in window, "waterfall loop around a staging load:\n" + window
