@@ -56,3 +56,23 @@ def test_phased_k_loop_keeps_its_pipeline(name, targs, nwait):
         assert re.search(r"buffer_load_dwordx4 v\d+, s\[\d+:\d+\], s\d+ offen lds", loop[i]), loop[i]
         window = "\n".join(loop[max(0, i - 6):i + 4])
         assert "v_readfirstlane" not in window and "s_and_saveexec" not in window, "waterfall loop around a staging load:\n" + window
+
+
+def test_built_library_has_no_scratch_outside_the_ab_variants():
+    """Every kernel of the built libgeo4d_hip.so, read from the code objects' metadata (tools/so_kernel_table.py): no spilled registers
+    (scratch) anywhere the product path goes - a spill inside an LDS-DMA loop costs a drained queue per reload. The four attention
+    instantiations that do spill are the A/B builds DESIGN.md lists (two query blocks per wave for the 4-byte element types, the
+    4-waves-per-SIMD occupancy build), not what ops.attention launches."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import so_kernel_table as skt
+    lib = os.path.join(ROOT, "geo4d_amd", "csrc", "libgeo4d_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(skt.READELF):
+        pytest.skip("library or llvm-readelf missing")
+    ks = skt.kernels(lib)
+    names = skt.demangle([k["name"] for k in ks])
+    assert len(ks) > 200 and sum(1 for n in names if n.startswith("conv_gemm_v3_kernel")) >= 20, len(ks)
+    allowed = {"flash_attn_kernel<float, 1, 2, 2>", "flash_attn_kernel<bf16x3_t, 1, 2, 2>", "flash_attn_kernel<bf16_t, 1, 1, 4>", "flash_attn_kernel<f16_t, 1, 1, 4>"}
+    bad = [(n, k["scratch"]) for k, n in zip(ks, names) if k["scratch"] and n not in allowed]
+    assert not bad, bad
+    assert all(k["vgpr"] <= 256 for k, n in zip(ks, names) if n.startswith("conv_gemm"))       # 8-wave tiles: two waves per SIMD
