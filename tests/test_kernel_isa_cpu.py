@@ -50,6 +50,37 @@ def test_phased_k_loop_keeps_its_pipeline(name, targs, nwait):
     assert not re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", text), "a drained DMA queue inside the K loop"
     counted = [int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)]
     assert len(counted) >= 7 and nwait in counted and min(counted) >= nwait - 1, counted
+    if name.startswith("160x320"):
+        # the emitted loop IS the designed schedule: per barrier interval (staging loads, fragment reads, MFMAs, counted wait) of the two
+        # slabs of a pair. 160x320 on 2 x 4 waves: A0 / A1 = 96 / 64 rows (2 / 1 pieces per wave), B0 / B1 = 192 / 128 rows (3 / 2 pieces),
+        # fragments A0 B0 = 3 blocks x 2 reads, A1 B1 = 2 x 2; quadrant MFMAs = blocks x blocks x 3 (bf16x3).
+        want = [(1, 4, 27, 7), (2, 4, 18, 7), (3, 6, 12, 8), (2, 4, 18, 7),       # even slab: (A0,B0) (A0,B1) (A1,B1) (A1,B0)
+                (1, 6, 18, 7), (2, 4, 27, 7), (2, 6, 18, 6), (3, 6, 12, 7)]       # odd slab:  (A0,B1) (A0,B0) (A1,B0) (A1,B1)
+        # the slab-pair loop = the loop header (LLVM's "Loop Header: Depth=2" annotation) followed by all 150 MFMAs of a pair; its text
+        # runs to the pair's closing barrier (blocks laid out behind it are the once-per-tile window set-up: no loads, reads or MFMAs)
+        heads = [i for i, l in enumerate(lines) if re.search(r"Loop Header: Depth=2\b", l)]
+        spans = [(sum("v_mfma" in x for x in lines[h:(heads[k + 1] if k + 1 < len(heads) else len(lines))]), h) for k, h in enumerate(heads)]
+        nm, h = max(spans)
+        assert nm == 150, spans
+        tail = lines[h:]
+        last_mfma = max(i for i, l in enumerate(tail) if "v_mfma" in l)
+        end = next(i for i in range(last_mfma, len(tail)) if "s_barrier" in tail[i])
+        body = tail[:end + 1]
+        got, cur = [], [0, 0, 0, None]
+        for l in body:
+            if "s_barrier" in l:
+                got.append(tuple(cur))
+                cur = [0, 0, 0, None]
+            elif "buffer_load_dwordx4" in l and " lds" in l:
+                cur[0] += 1
+            elif "ds_read_b128" in l:
+                cur[1] += 1
+            elif "v_mfma" in l:
+                cur[2] += 1
+            elif re.search(r"s_waitcnt vmcnt\((\d+)\)", l):
+                cur[3] = int(re.search(r"vmcnt\((\d+)\)", l).group(1))
+        assert cur[:3] == [0, 0, 0], cur               # nothing but the back branch after the last barrier
+        assert got == want, got
     loads = [i for i, l in enumerate(loop) if "buffer_load_dwordx4" in l and " lds" in l]
     assert len(loads) >= 8, len(loads)
     for i in loads:

@@ -28,7 +28,8 @@ def classify(op):
     return "other"
 
 
-def loop_mix(lines):
+def innermost_mfma_loop(lines):
+    """The shortest backward-branch loop of the listing that contains an MFMA: [header label .. back branch]."""
     labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
     best = None
     for i, l in enumerate(lines):
@@ -37,6 +38,11 @@ def loop_mix(lines):
             body = lines[labels[m.group(1)]:i + 1]
             if any("v_mfma" in b for b in body) and (best is None or len(body) < len(best)):
                 best = body
+    return best
+
+
+def loop_mix(lines):
+    best = innermost_mfma_loop(lines)
     mix, forms = {}, {}
     for b in best or []:
         t = b.strip().split()
