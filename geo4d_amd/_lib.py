@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GEO4D_HIP_LIB: load another build of the SAME library (A/B builds of a kernel: tools/gpu_r2k.sh); the ABI handshake below still applies
 LIB_PATH = os.environ.get("GEO4D_HIP_LIB") or os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 
@@ -47,7 +47,7 @@ class GroupNorm(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("ldx", C.c_long), ("ldy", C.c_long),
         ("F", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("frames_per_stat", C.c_int),
-        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("barrier", C.c_void_p), ("counters", C.c_void_p), ("split_out", C.c_int),
+        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("split_out", C.c_int),
     ]
 
 
@@ -58,7 +58,7 @@ class Attention(C.Structure):
         ("ldq", C.c_long), ("ldo", C.c_long), ("ldk", C.c_long * 2), ("ldvt", C.c_long * 2), ("vt_bs", C.c_long * 2),
         ("Nk", C.c_int * 2), ("kv_div", C.c_int * 2),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("nseg", C.c_int), ("head_dim", C.c_int), ("dtype", C.c_int),
-        ("scale", C.c_float), ("split_out", C.c_int), ("variant", C.c_int),
+        ("scale", C.c_float), ("split_out", C.c_int), ("variant", C.c_int), ("qkv_split", C.c_int),
     ]
 
 

@@ -166,6 +166,9 @@ class GroupAligner:
         if any(not any(i == img for i in e_all) for img in range(self.n)):
             raise ValueError("every image must belong to at least one window")
         self.shard = shard
+        if shard is not None and not shard.local_groups:
+            raise ValueError(f"rank {shard.rank} of {shard.world} owns no window of this {G}-window clip: build the shard with "
+                             "align_dist.make_shard (it falls back to the replicated optimisation when windows < ranks)")
         local = set(range(G)) if shard is None else set(shard.local_groups)
         self.local_groups = sorted(local)
         self.primary = shard is None or shard.primary          # evaluates the pose-only terms (temporal smoothing, trajectory)
@@ -669,7 +672,10 @@ def _init_pnp(self, pred, conf, focal, raymaps, niter_PnP, seed):
                 done.add(i)
             if im_focals[i] is None:
                 im_focals[i] = ray_focal(g, k)
-            res = run_pnp(i, g, k)
+            # the PnP result is only used where pose / focal are still unset (both assignments below are `is None`-guarded, as in the
+            # reference) and the solver's sampler is re-seeded per call: skipping the call for already-initialised images (~3 of 4
+            # occurrences at stride 4) changes nothing but the start-up time (host-side numpy RANSAC)
+            res = run_pnp(i, g, k) if (im_poses[i] is None or im_focals[i] is None) else None
             if res:
                 if im_poses[i] is None:
                     im_poses[i] = torch.from_numpy(res[1]).float().to(self.dev)
@@ -732,8 +738,8 @@ def post_optimization(slices, maps, traj, args=None, conf_optimize=True, lr=0.03
     shard = None
     if sharded or (sharded is None and torch.distributed.is_available() and torch.distributed.is_initialized()
                    and torch.distributed.get_world_size() > 1):
-        from .align_dist import AlignShard
-        shard = AlignShard(groups, 1 + max(max(g) for g in groups))
+        from .align_dist import make_shard
+        shard = make_shard(groups, 1 + max(max(g) for g in groups))     # None when the clip has fewer windows than ranks (replicated run)
     scene = GroupAligner(groups, torch.stack([p["pts3d"] for p in post]), conf, shard=shard,
                          shared_focal=not get("not_shared_focal", False) and not get("use_gt_focal", False),
                          temporal_smoothing_weight=get("temporal_smoothing_weight", 0.015), translation_weight=get("translation_weight", 1.0),

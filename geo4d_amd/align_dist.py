@@ -30,6 +30,15 @@ def partition_windows(num_windows, rank, world):
     return list(range(lo, lo + base + (1 if rank < extra else 0)))
 
 
+def make_shard(groups, n_images, rank=None, world=None, group=None):
+    """The shard `post_optimization` runs under, or None = replicated optimisation: with fewer windows than ranks (a clip shorter than
+    16 + 4 (world - 1) frames at stride 4) some ranks would own NO window - an empty slot list, which the fused residual kernel
+    refuses while the other ranks wait in the per-iteration all-reduce. Such a clip is seconds of work: every rank runs the whole
+    optimisation (bit-identical results on every rank, no collective). The decision depends on (G, world) only, so all ranks agree."""
+    shard = AlignShard(groups, n_images, rank=rank, world=world, group=group)
+    return shard if shard.active and len(shard.groups) >= shard.world else None
+
+
 class AlignShard:
     def __init__(self, groups, n_images, rank=None, world=None, group=None):
         self.group = group

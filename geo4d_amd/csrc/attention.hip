@@ -27,7 +27,11 @@ namespace {
 // 256-byte f32 rows: slot = chunk ^ (row & 15)).
 // QB = 32-row query blocks per wave (1: 128 query rows per workgroup; 2: 256 — every K / V^T fragment read from LDS feeds
 // two MFMAs, and a launch needs half as many wave-slots). OCC = waves per SIMD the register allocator must leave room for.
-template <typename T, int NSEG, int QB, int OCC>
+// PS (bf16x3 only): q, K and V^T arrive in the producers' PRE-SPLIT format (geo4d_attention_t.qkv_split: per 8 elements of a row
+// [8 x bf16 hi | 8 x bf16 lo], the same 4 bytes per element and the same 16-byte chunk addresses), so the kernel does not split K / V^T
+// fragments per tile and wave (16 of its ~20 split8_bf16 per 64-key tile: ~30 % of the loop's VALU instructions). Same arithmetic as
+// the in-kernel split -> bit-identical results.
+template <typename T, int NSEG, int QB, int OCC, bool PS = false>
 __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attention_t p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = (int)sizeof(T);
@@ -41,6 +45,7 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
     constexpr int PCH = X3 ? 2 : 16 / EPC;        // P chunks per 32-key block (x3: 16 keys per bf16 MFMA step, like the 16-bit types)
     constexpr int NQ = X3 ? 4 : NKK;              // MFMA k-steps over d = 64 (16 per step for the bf16 MFMA of the x3 path)
     static_assert(QB == 1 || NSEG == 1, "two query blocks per wave are built for single-segment (self) attention only");
+    static_assert(!PS || X3, "pre-split inputs are a bf16x3 option");
     __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];   // [buf][K | Vt]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,7 +70,8 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
                     c0 = *(const u32x4*)(qp + (4 * s2 + 2 * g) * EPC);
                     c1 = *(const u32x4*)(qp + (4 * s2 + 2 * g + 1) * EPC);
                 }
-                split8_bf16(c0, c1, qf[qb][s2], ql[qb][s2]);
+                if constexpr (PS) { qf[qb][s2] = c0; ql[qb][s2] = c1; }      // chunk pair (2j, 2j+1) = (hi, lo) of d = 8j .. 8j+7
+                else split8_bf16(c0, c1, qf[qb][s2], ql[qb][s2]);
             }
         } else {
 #pragma unroll
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
             const int row = (wave * NDMA + i) * RPI + srow;            // key index in tile / d index
             const int chunk = sslot ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15));   // logical 16-byte chunk fetched into this slot
             krow[i] = row;
-            vkey[i] = chunk * EPC;                                      // first key of this lane's V^T chunk
+            vkey[i] = PS ? (chunk >> 1) * 8 : chunk * EPC;              // first key of this lane's V^T chunk (pre-split: hi | lo chunks of 8 keys)
             ksrc[i] = kp + (long)row * ldk + chunk * EPC;
             vsrc[i] = vp + (long)row * ldvt + chunk * EPC;
         }
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
                     const u32x4 c0 = *(const u32x4*)(krow_ + (((4 * s2 + 2 * g) ^ swz) << 4));
                     const u32x4 c1 = *(const u32x4*)(krow_ + (((4 * s2 + 2 * g + 1) ^ swz) << 4));
                     u32x4 kh, kl;
-                    split8_bf16(c0, c1, kh, kl);
+                    if constexpr (PS) { kh = c0; kl = c1; }
+                    else split8_bf16(c0, c1, kh, kl);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) mma_x3(st[qb][kb], kh, kl, qf[qb][s2], ql[qb][s2]);
                 }
@@ -253,10 +260,22 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
                         const char* vrow = vtile + (d * 32 + li) * ROWB;
-                        const u32x4 c0 = *(const u32x4*)(vrow + (((8 * kb + 4 * c + g) ^ swz) << 4));
-                        const u32x4 c1 = *(const u32x4*)(vrow + (((8 * kb + 4 * c + 2 + g) ^ swz) << 4));
                         u32x4 vh, vl;
-                        split8_bf16(c0, c1, vh, vl);
+                        if constexpr (PS) {
+                            // keys 32 kb + 16 c + 4 g + {0..3} and + 8: positions 4g .. 4g+3 of the 8-key groups 4 kb + 2 c and + 1, whose hi / lo
+                            // halves are the 16-byte chunks 2 G and 2 G + 1 of the row: four 8-byte reads (2-way bank conflict: 32 lanes x 8 B
+                            // of 256-byte rows with one half-select per lane group; the b128 alternative reads twice the bytes for the same cycles)
+                            const u32x2 h0 = *(const u32x2*)(vrow + (((8 * kb + 4 * c) ^ swz) << 4) + 8 * g);
+                            const u32x2 l0 = *(const u32x2*)(vrow + (((8 * kb + 4 * c + 1) ^ swz) << 4) + 8 * g);
+                            const u32x2 h1 = *(const u32x2*)(vrow + (((8 * kb + 4 * c + 2) ^ swz) << 4) + 8 * g);
+                            const u32x2 l1 = *(const u32x2*)(vrow + (((8 * kb + 4 * c + 3) ^ swz) << 4) + 8 * g);
+                            vh = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                            vl = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                        } else {
+                            const u32x4 c0 = *(const u32x4*)(vrow + (((8 * kb + 4 * c + g) ^ swz) << 4));
+                            const u32x4 c1 = *(const u32x4*)(vrow + (((8 * kb + 4 * c + 2 + g) ^ swz) << 4));
+                            split8_bf16(c0, c1, vh, vl);
+                        }
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) mma_x3(oa[qb][d], vh, vl, ph[qb], pl[qb]);
                     }
@@ -460,6 +479,13 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     if (!p.zeros || ((uintptr_t)p.zeros % 16)) { geo4d_set_error("attention: `zeros` must point at 16 zero bytes"); return GEO4D_EINVAL; }
     if (p.H > 65535 || p.B > 65535) { geo4d_set_error("attention: grid too large"); return GEO4D_EINVAL; }
     if (p.split_out && esz != 4) { geo4d_set_error("attention: split_out is the producer format of the 4-byte storage modes (f32 / bf16x3)"); return GEO4D_EINVAL; }
+    if (p.qkv_split) {
+        if (p.dtype != GEO4D_BF16X3 || p.nseg != 1 || (p.Nk[0] % 8) || (p.ldq % 8) || (p.ldk[0] % 8) || (p.ldvt[0] % 8) || (p.vt_bs[0] % 8) ||
+            ((uintptr_t)p.q % 32) || ((uintptr_t)p.k[0] % 32) || ((uintptr_t)p.vt[0] % 32)) {
+            geo4d_set_error("attention: qkv_split needs dtype bf16x3, one key/value set, Nk % 8 == 0, leading dimensions % 8 == 0 and 32-byte aligned bases");
+            return GEO4D_EINVAL;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     // variant: 0 = host default; explicit: 1 = 128 rows / workgroup at 3 waves per SIMD (round-1 kernel), 2 = the same at 4 waves
     // per SIMD (128-VGPR budget), 3 = 256 rows / workgroup, two query blocks per wave (self-attention only)
@@ -483,7 +509,11 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     } while (0)
     switch (p.dtype) {
         case GEO4D_F32: ATT_TYPED(float); break;
-        case GEO4D_BF16X3: ATT_TYPED(bf16x3_t); break;
+        case GEO4D_BF16X3:
+            if (p.qkv_split && variant == 3) hipLaunchKernelGGL((flash_attn_kernel<bf16x3_t, 1, 2, 2, true>), grid, dim3(256), 0, st, p);
+            else if (p.qkv_split) hipLaunchKernelGGL((flash_attn_kernel<bf16x3_t, 1, 1, 1, true>), grid, dim3(256), 0, st, p);
+            else ATT_TYPED(bf16x3_t);
+            break;
         case GEO4D_BF16:
             if (p.nseg == 1 && variant == 2) ATT_LAUNCH(bf16_t, 1, 1, 4);
             else ATT_TYPED(bf16_t);

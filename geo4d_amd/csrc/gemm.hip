@@ -57,9 +57,9 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     if (p.dtype != GEO4D_BF16X3 && (p.a_split || p.w_split)) { geo4d_set_error("conv_gemm: a_split / w_split are bf16x3 (dtype 3) options"); return GEO4D_EINVAL; }
     if (p.o_split) {
         const int nst = p.act == 2 ? p.N / 2 : p.N;
-        if (p.dtype != GEO4D_BF16X3 || p.out_dtype != GEO4D_F32 || p.act != 2 || !p.a_split || !p.w_split || p.split_k > 1 || p.out_nchw || p.R || p.gn_colsum ||
-            (nst % 8) || (p.ldo % 4) || (p.o_bs % 4) || ((uintptr_t)p.O % 16)) {
-            geo4d_set_error("conv_gemm: o_split needs the GEGLU epilogue of a pre-split x pre-split bf16x3 launch, f32 row-major output, stored columns % 8 == 0, aligned rows, no split-K");
+        if (p.dtype != GEO4D_BF16X3 || p.out_dtype != GEO4D_F32 || !p.a_split || !p.w_split || p.split_k > 1 || p.out_nchw || p.gn_colsum ||
+            (nst % 8) || (p.ldo % 8) || (p.o_bs % 8) || ((uintptr_t)p.O % 32)) {
+            geo4d_set_error("conv_gemm: o_split needs a pre-split x pre-split bf16x3 launch, f32 row-major output, stored columns % 8 == 0, 32-byte aligned rows, no split-K");
             return GEO4D_EINVAL;
         }
     }

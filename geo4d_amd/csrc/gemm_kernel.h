@@ -188,9 +188,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
 #pragma unroll
             for (int j = 0; j < 2; ++j) foffx[s2][j] = li * PITCH + (((4 * s2 + 2 * g + j) ^ ((li >> 1) & 7)) << 4);
     }
-    // debug_ablate = 1 (tools/gemm_bench.py --ablate): treat raw f32 operands as if pre-split, i.e. skip the in-register split -
-    // WRONG numbers, used only to measure what the split's VALU work costs
-    const bool a_split = HOT ? (HOT == 2) : (p.a_split != 0 || p.debug_ablate == 1), w_split = HOT ? true : (p.w_split != 0 || p.debug_ablate == 1);
+    const bool a_split = HOT ? (HOT == 2) : (p.a_split != 0), w_split = HOT ? true : (p.w_split != 0);
     auto compute_slab = [&](int buf) {
         const char* abase = smem + buf * (BM + BN) * PITCH + (wr * WTM) * PITCH;
         const char* bbase = smem + buf * (BM + BN) * PITCH + (BM + wc * WTN) * PITCH;
@@ -252,41 +250,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const geo4d_con
         }
     };
 
-    if constexpr (ST == 2) {
-        if (nslab > 0) {
-            fetch_pix();
-            issue_slab(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA must be drained explicitly before the barrier
-        __syncthreads();
-        for (int s = 0; s < nslab; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nslab) issue_slab(buf ^ 1);   // all pieces up front: measured faster than spreading them over the MFMA groups
-            compute_slab(buf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (explicit: never rely on hipcc for DMA)
-            __syncthreads();                                    // ... for every wave, and everyone is done reading this one
-        }
-    } else {
-        // ST-deep ring (ST >= 3), DMA ST-1 stages ahead, ONE barrier per stage, counted vmcnt (never 0 in the steady state):
-        //   wait(stage s landed: at most the DMAs of the ST-2 younger stages still in flight) -> barrier (everyone's part of
-        //   stage s landed, everyone finished reading stage s-1) -> issue stage s+ST-1 into the buffer of s-1 -> compute s.
-        // LDS-DMA loads retire in order, so vmcnt(n) is "all but the youngest n".
-        static_assert((ST - 2) * NP <= 63, "vmcnt immediate is 6 bits");
-        for (int s = 0; s < ST - 1; ++s)
-            if (s < nslab) {
-                if (s == 0) fetch_pix();
-                issue_slab(s);
-            }
-        int buf = 0;
-        for (int s = 0; s < nslab; ++s) {
-            if (nslab - 1 - s >= ST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (s + ST - 1 < nslab) issue_slab(buf == 0 ? ST - 1 : buf - 1);
-            compute_slab(buf);
-            buf = buf == ST - 1 ? 0 : buf + 1;
-        }
-        __syncthreads();   // all waves done with the ring before the epilogue reuses it
+    static_assert(ST == 2, "two ring stages (deeper rings never beat their 2-stage twins: profiles/r01_gemm_tiles.md; removed in round 4)");
+    if (nslab > 0) {
+        fetch_pix();
+        issue_slab(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA must be drained explicitly before the barrier
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) issue_slab(buf ^ 1);   // all pieces up front: measured faster than spreading them over the MFMA groups
+        compute_slab(buf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (explicit: never rely on hipcc for DMA)
+        __syncthreads();                                    // ... for every wave, and everyone is done reading this one
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
@@ -576,8 +552,8 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     }
     int rc;
     if constexpr (IsX3<T>::value) {
-        if (p.w_split && !p.a_split && p.debug_ablate == 0) rc = launch_kernel<T, BM, BN, WM, WN, ST, 1>(p, splits, stream);
-        else if (p.w_split && p.a_split && p.debug_ablate == 0) rc = launch_kernel<T, BM, BN, WM, WN, ST, 2>(p, splits, stream);
+        if (p.w_split && !p.a_split) rc = launch_kernel<T, BM, BN, WM, WN, ST, 1>(p, splits, stream);
+        else if (p.w_split && p.a_split) rc = launch_kernel<T, BM, BN, WM, WN, ST, 2>(p, splits, stream);
         else rc = launch_kernel<T, BM, BN, WM, WN, ST, 0>(p, splits, stream);
     } else {
         rc = launch_kernel<T, BM, BN, WM, WN, ST, 0>(p, splits, stream);
@@ -591,10 +567,10 @@ int launch_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     return GEO4D_OK;
 }
 
-// tile hints 21..39 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups) are instantiated in their own
+// tile hints 22..28 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups) are instantiated in their own
 // translation units (gemm_v2_*.hip) so that the two kernel generations compile in parallel
 template <typename T> int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream);
-// tile hints 71..74 (gemm_kernel_v3.h: the same with a phased, counted-wait K loop on staggered wave groups): gemm_v3_*.hip
+// tile hints 71..74 (gemm_kernel_v3.h: the same with a phased, counted-wait K loop): gemm_v3_*.hip
 template <typename T> int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream);
 
 // Tile choice: score = MFMA efficiency of the tile shape x useful fraction x how full the last wave of
@@ -609,18 +585,17 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     if (p.tile_hint >= 21) return launch_v2_typed<T>(p, stream);
     if (p.o_split) {     // the pre-split output format lives in the register epilogue of the second-generation kernel only
         geo4d_conv_gemm_t q = p;
-        q.tile_hint = p.tile_hint == 13 ? 22 : (p.tile_hint == 11 || p.tile_hint == 12) ? 21 : p.tile_hint == 3 ? 27 : 25;
+        q.tile_hint = (p.tile_hint == 13 || p.tile_hint == 11) ? 22 : p.tile_hint == 16 ? 23 : p.tile_hint == 3 ? 27 : p.tile_hint == 4 ? 28 : 25;
         return launch_v2_typed<T>(q, stream);
     }
     if (p.tile_hint >= 11) {
         // explicit big-tile / deep-ring configurations, chosen by the host tuning table only. What they trade:
         // a CU can hold at most ~128 KB of LDS-DMA destinations, and a stage lands ~1 us after it is issued, so the
         // flops a CU can retire per microsecond are (bytes in flight) x (flops per byte of the tile shape).
-        //   11: 256x128, 8 waves, 2 stages     12: 256x128, 8 waves, 3 stages (2 stages in flight)
-        //   13: 256x256, 8 waves, 2 stages (128 flop/B)     14: 128x128, 4 waves, 4 stages (3 in flight)
+        //   11: 256x128, 8 waves     13: 256x256, 8 waves (128 flop/B)
         //   16: 160x320, 10 waves (M = 40960, N = 320: 256 tiles = one per CU, each input row and each weight read once per tile)
-        // Measured (profiles/r01_gemm_tiles.md): deeper rings (12, 14) never beat their 2-stage twins - the fill rate per CU
-        // does not grow with more DMAs in flight - while the fatter tiles (11, 13) do: fewer L2->LDS bytes per flop.
+        // Measured (profiles/r01_gemm_tiles.md): deeper rings (former hints 12, 14) never beat their 2-stage twins - the fill rate
+        // per CU does not grow with more DMAs in flight - while the fatter tiles (11, 13) do: fewer L2->LDS bytes per flop.
         int sp = 1;
         if (p.split_k > 1) {
             if (!p.workspace || p.act == 2 || p.out_nchw || (p.N % 8) || (size_t)p.split_k * p.batch * p.M * p.N * 4 > p.workspace_bytes ||
@@ -632,9 +607,7 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
         }
         switch (p.tile_hint) {
             case 11: return launch_cfg<T, 256, 128, 4, 2, 2>(p, sp, stream);
-            case 12: return launch_cfg<T, 256, 128, 4, 2, 3>(p, sp, stream);
             case 13: return launch_cfg<T, 256, 256, 4, 2, 2>(p, sp, stream);
-            case 14: return launch_cfg<T, 128, 128, 2, 2, 4>(p, sp, stream);
             case 16: return launch_cfg<T, 160, 320, 5, 2, 2>(p, sp, stream);   // 10 waves: all 320 columns of the level-0 layers in ONE tile
             case 17: return launch_cfg<T, 160, 160, 5, 1, 2>(p, sp, stream);   // 5 waves: M = 10240, N = 640 -> 256 tiles
         }

@@ -124,7 +124,8 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
 #pragma unroll
                         for (int j = 0; j < 4; ++j) e[j] += r[j];
                     }
-                    *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
+                    if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, n >> 2, e);     // (OSPLIT launches are never partial)
+                    else *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
                 } else {
                     if (has_res) {
                         const u32x2 r = *(const u32x2*)((const unsigned short*)p.R + rbase + (long)m * p.ldr + n);
@@ -152,17 +153,14 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
     }
 }
 
-template <int BM, int BN, int NA>
-constexpr int v2_smem_bytes() { return (NA * BM + 2 * BN) * PITCH + BM * MAXTAP * 4; }
+template <int BM, int BN>
+constexpr int v2_smem_bytes() { return (2 * BM + 2 * BN) * PITCH + BM * MAXTAP * 4; }
 
-// ABL (profiling builds only, tile hints 40..69, WRONG results by construction): 1 = no LDS-DMA after a tile's first slab (compute on
-// stale LDS), 2 = LDS-DMA + barriers only (no fragment reads, no MFMA), 3 = MFMA only (fragments read once per tile, DMA off after the
-// first slab), 4 = skip the in-register hi/lo split
-// NA = number of A-panel (activation) buffers in the ring: 2 = both panels double-buffered; 3 = the gathered A panel runs TWO slabs
-// ahead (its rows come from HBM / the Infinity Cache, measured landing time of a lone 60 KB slab: 1.05-1.44 us against 1.2 us of
-// MFMA work per bf16x3 slab) while the L2-resident weight panel stays one slab ahead; 160 KB of LDS does not hold three full stages.
-// OSPLIT: the GEGLU epilogue writes the pre-split operand format (o_split; a separate instantiation: the extra epilogue code costs registers)
-template <typename T, int BM, int BN, int WM, int WN, int HOT, int NA = 2, int ABL = 0, bool OSPLIT = false>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
+// OSPLIT: the epilogue writes the pre-split operand format (o_split: the GEGLU output feeding ff.net.2, q | k and V^T feeding the
+// attention kernel); a separate instantiation (the extra epilogue code costs registers).
+// (Round 3 also built a third A-panel buffer - the gathered panel two slabs ahead - and ablation builds of this loop; measured: the
+// third buffer never beat two, profiles/r03_gemm_v2_explore_and_ablation.md. Removed from the shipped sources in round 4.)
+template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_conv_gemm_t p, const int splits, const int tiles_mn) {
     constexpr int NT = WM * WN * 64;
     constexpr int EPC = Elem<T>::EPC;
@@ -171,10 +169,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
     constexpr int MB = WTM / 16, NB = WTN / 16;       // 16x16 accumulator blocks per wave
     constexpr int RSTEP = NT / 8;                     // panel rows covered by one staging pass of the workgroup
     constexpr int ACH = (BM + RSTEP - 1) / RSTEP, BCH = (BN + RSTEP - 1) / RSTEP;
-    constexpr int RING = (NA * BM + 2 * BN) * PITCH;
-    static_assert(NA == 2 || NA == 3, "2 or 3 A-panel buffers");
+    constexpr int RING = (2 * BM + 2 * BN) * PITCH;
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && BM % 8 == 0 && BN % 8 == 0, "wave tiles are multiples of 16");
-    static_assert(!std::is_same<T, float>::value, "v2 serves the 16-bit MFMA forms (bf16, f16, bf16x3)");
+    static_assert(!std::is_same<T, float>::value, "v2 serves the 16-bit MFMA forms (bf16, bf16x3)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* rowpix = (int*)(smem + RING);
 
@@ -275,7 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         if (ntap > 1 && c0 < p.Cin) fetch_pix();
     };
     auto issue_B = [&](int bb) {
-        char* base = smem + (NA * BM + bb * BN) * PITCH + wave * 1024;
+        char* base = smem + (2 * BM + bb * BN) * PITCH + wave * 1024;
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             if ((BCH * RSTEP == BN) || (wave * 8 + i * RSTEP < BN)) {
@@ -286,9 +283,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         }
         if (++tapB == ntap) { tapB = 0; c0B += BK; }
     };
-    // A pieces this wave issues per slab (ragged panels: the last pass covers only the first waves): the counted vmcnt of NA = 3
-    const int nA = (ACH * RSTEP == BM || wave * 8 + (ACH - 1) * RSTEP < BM) ? ACH : ACH - 1;
-
     f32x4 acc[MB][NB];
     // fragment offsets inside a 16-row block: lane (lr, lq) reads row lr; 16-bit types: chunk 4h + lq of half h; bf16x3: chunks 2lq, 2lq + 1
     const int fkey = swz_key<T>(lr);
@@ -301,43 +295,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         foff[1] = lr * PITCH + (((4 + lq) ^ fkey) << 4);
     }
     const bool a_split = HOT ? (HOT == 2) : (p.a_split != 0), w_split = HOT ? true : (p.w_split != 0);
-    u32x4 kah[ABL == 3 ? MB : 1], kal[ABL == 3 ? MB : 1], kbh[ABL == 3 ? NB : 1], kbl[ABL == 3 ? NB : 1];   // ABL 3 only
-    auto compute_slab = [&](int ab, int bb, bool first) {
-        const char* abase = smem + (ab * BM + wr * WTM) * PITCH;
-        const char* bbase = smem + (NA * BM + bb * BN + wc * WTN) * PITCH;
-        if constexpr (ABL == 2) return;
+    auto compute_slab = [&](int buf) {
+        const char* abase = smem + (buf * BM + wr * WTM) * PITCH;
+        const char* bbase = smem + (2 * BM + buf * BN + wc * WTN) * PITCH;
         if constexpr (IsX3<T>::value) {
             // one 128-byte slab = 32 k = ONE 16x16x32 step; the activation fragments are split once and reused by every column block
             u32x4 ah[MB], al[MB];
 #pragma unroll
             for (int a = 0; a < MB; ++a) {
-                if constexpr (ABL == 3) {            // real fragments of the tile's first slab, kept in registers: no LDS traffic, no split
-                    if (first) {
-                        split8_bf16(*(const u32x4*)(abase + a * 16 * PITCH + foff[0]), *(const u32x4*)(abase + a * 16 * PITCH + foff[1]), kah[a], kal[a]);
-                    }
-                    ah[a] = kah[a]; al[a] = kal[a];
-                    asm volatile("" : "+v"(ah[a]), "+v"(al[a]));
-                    continue;
-                }
                 const u32x4 x0 = *(const u32x4*)(abase + a * 16 * PITCH + foff[0]);
                 const u32x4 x1 = *(const u32x4*)(abase + a * 16 * PITCH + foff[1]);
-                if (a_split || ABL == 4) { ah[a] = x0; al[a] = x1; }
+                if (a_split) { ah[a] = x0; al[a] = x1; }
                 else split8_bf16(x0, x1, ah[a], al[a]);
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                u32x4 y0, y1;
-                if constexpr (ABL == 3) {
-                    if (first) {
-                        kbh[b] = *(const u32x4*)(bbase + b * 16 * PITCH + foff[0]);
-                        kbl[b] = *(const u32x4*)(bbase + b * 16 * PITCH + foff[1]);
-                    }
-                    y0 = kbh[b]; y1 = kbl[b];
-                    asm volatile("" : "+v"(y0), "+v"(y1));
-                } else {
-                    y0 = *(const u32x4*)(bbase + b * 16 * PITCH + foff[0]);
-                    y1 = *(const u32x4*)(bbase + b * 16 * PITCH + foff[1]);
-                }
+                const u32x4 y0 = *(const u32x4*)(bbase + b * 16 * PITCH + foff[0]);
+                const u32x4 y1 = *(const u32x4*)(bbase + b * 16 * PITCH + foff[1]);
                 u32x4 bh, bl;
                 if (w_split) { bh = y0; bl = y1; }
                 else split8_bf16(y0, y1, bh, bl);
@@ -369,9 +343,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
     long w = xcd_remap((long)blockIdx.x, G);           // each XCD walks a contiguous range of every round of G tiles
     if (w >= total) return;
     setup_tile(w);
-    auto prologue = [&]() {                                 // the tile's first slab (and, with 3 A buffers, the second A panel)
+    auto prologue = [&]() {                                 // the tile's first slab
         if (nslab > 0) { issue_A(0); issue_B(0); }
-        if (NA == 3 && nslab > 1) issue_A(1);
     };
     prologue();
     while (true) {
@@ -380,37 +353,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int ns = nslab;
-        if constexpr (NA == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is drained explicitly before every barrier
-            __syncthreads();
-            for (int s = 0; s < ns; ++s) {
-                const int buf = s & 1;
-                if (s + 1 < ns && ABL != 1 && ABL != 3) { issue_A(buf ^ 1); issue_B(buf ^ 1); }
-                compute_slab(buf, buf, s == 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                               // next slab landed for every wave, everyone is done reading this one
-            }
-        } else {
-            // ONE raw barrier per slab, counted vmcnt (LDS-DMA retires in order: vmcnt(n) = all but the youngest n): at the top of
-            // slab s the outstanding pieces are B(s) then A(s+1); A(s) landed a slab ago. After the barrier everyone has finished
-            // reading slab s-1, so B buffer (s+1)&1 and A buffer (s+2)%3 are free.
-            int ab = 0;
-            for (int s = 0; s < ns; ++s) {
-                if (s + 1 < ns) {
-                    if (nA == ACH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ACH) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ACH - 1) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();
-                if (ABL != 1 && ABL != 3) {
-                    if (s + 1 < ns) issue_B((s + 1) & 1);
-                    if (s + 2 < ns) issue_A(ab == 0 ? 2 : ab - 1);          // (s + 2) % 3
-                }
-                compute_slab(ab, s & 1, s == 0);
-                ab = ab == 2 ? 0 : ab + 1;
-            }
-            __syncthreads();                                   // everyone is done with the ring before the next tile's prologue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is drained explicitly before every barrier
+        __syncthreads();
+        for (int s = 0; s < ns; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < ns) { issue_A(buf ^ 1); issue_B(buf ^ 1); }
+            compute_slab(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                               // next slab landed for every wave, everyone is done reading this one
         }
         const int e_tm = tm, e_tn = tn, e_kz = kz;
         const long e_bz = bz;
@@ -427,12 +377,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
 }
 
 // resident workgroups per launch = CUs x workgroups that fit a CU (queried once per kernel instantiation)
-template <typename T, int BM, int BN, int WM, int WN, int HOT, int NA = 2, int ABL = 0, bool OSPLIT = false>
+template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false>
 int launch_v2_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
-    constexpr int smem = v2_smem_bytes<BM, BN, NA>();
+    constexpr int smem = v2_smem_bytes<BM, BN>();
     static_assert(smem <= 160 * 1024, "LDS");
     static int resident = 0;
-    auto kern = conv_gemm_v2_kernel<T, BM, BN, WM, WN, HOT, NA, ABL, OSPLIT>;
+    auto kern = conv_gemm_v2_kernel<T, BM, BN, WM, WN, HOT, OSPLIT>;
     if (!resident) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
@@ -461,7 +411,15 @@ int launch_v2_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream)
     return GEO4D_OK;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NA = 2>
+// o_split (bf16x3, pre-split x pre-split operands only): the output in the producers' pre-split format - needs whole 8-column groups
+// and 16-byte aligned rows, has no split-K (the reduce kernel writes plain f32) and no residual-free restrictions otherwise
+inline bool o_split_ok(const geo4d_conv_gemm_t& p, int splits) {
+    const long nout = p.act == 2 ? (p.N >> 1) : p.N;
+    return splits == 1 && p.w_split && p.a_split && (nout & 7) == 0 && (p.ldo & 7) == 0 && ((uintptr_t)p.O % 32) == 0 &&
+           (p.batch == 1 || (p.o_bs & 7) == 0) && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R % 16) == 0 && (p.batch == 1 || (p.r_bs & 3) == 0)));
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
 int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     if (p.act == 2 && ((BN / WN / 16) % 4)) {
         geo4d_set_error("conv_gemm v2: GEGLU needs wave tiles that are a multiple of 64 columns wide");
@@ -470,30 +428,28 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
     if constexpr (IsX3<T>::value) {
         if (p.o_split) {
-            if constexpr ((BN / WN / 16) % 4 == 0) {
-                if (p.act == 2 && p.w_split && p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 2, NA, 0, true>(p, splits, stream);
-            }
-            geo4d_set_error("conv_gemm: o_split is built for the GEGLU epilogue (act 2) of pre-split x pre-split launches on GEGLU-capable tiles");
+            if (o_split_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+            geo4d_set_error("conv_gemm: o_split needs pre-split x pre-split operands, no split-K, N % 8 == 0 and 32-byte aligned output rows");
             return GEO4D_EINVAL;
         }
-        if (p.w_split && !p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 1, NA>(p, splits, stream);
-        if (p.w_split && p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 2, NA>(p, splits, stream);
+        if (p.w_split && !p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 1>(p, splits, stream);
+        if (p.w_split && p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
     }
-    return launch_v2_kernel<T, BM, BN, WM, WN, 0, NA>(p, splits, stream);
+    return launch_v2_kernel<T, BM, BN, WM, WN, 0>(p, splits, stream);
 }
 
-// tile hints 21..29: 16x16x32 MFMA, register epilogue, persistent workgroups
-//   21: 256x128, 8 waves (64x64 wave tiles)     22: 256x256, 8 waves (64x128)      23: 160x320, 8 waves (80x80)
-//   24: 160x160, 4 waves (80x80)                25: 128x128, 4 waves (64x64)       26: 128x64, 4 waves (64x32)
-//   27: 64x128, 4 waves (32x64)                 28: 64x64, 4 waves (32x32)         29: 128x256, 8 waves (64x64)
+// tile hints of the second generation (16x16x32 MFMA, register epilogue, persistent workgroups). Round 4 kept the five the measured
+// table selects (profiles/r04_gemm_census_vendor.md); 21 / 24 / 26 / 29 and the three-A-buffer twins 31..39 are gone:
+//   22: 256x256, 8 waves (64x128 wave tiles)    23: 160x320, 8 waves (80x80)    25: 128x128, 4 waves (64x64)
+//   27: 64x128, 4 waves (32x64)                 28: 64x64, 4 waves (32x32)
 template <typename T>
 int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
-    if constexpr (std::is_same<T, float>::value) {
-        geo4d_set_error("conv_gemm: tile hints 21..29 serve bf16 / f16 / bf16x3 (the exact-f32 mode stays on hints 0..17)");
+    if constexpr (std::is_same<T, float>::value || std::is_same<T, f16_t>::value) {
+        geo4d_set_error("conv_gemm: tile hints 22..28 serve bf16 / bf16x3 (the exact-f32 and the f16 modes stay on hints 0..17)");
         return GEO4D_EINVAL;
     } else {
-        if (p.out_nchw || p.gn_colsum || p.debug_ablate == 1) {
-            geo4d_set_error("conv_gemm: tile hints 21..29 have no NCTHW / gn_colsum epilogue");
+        if (p.out_nchw || p.gn_colsum) {
+            geo4d_set_error("conv_gemm: tile hints 22..28 have no NCTHW / gn_colsum epilogue");
             return GEO4D_EINVAL;
         }
         int sp = 1;
@@ -506,37 +462,12 @@ int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             sp = p.split_k;
         }
         switch (p.tile_hint) {
-            case 21: return launch_v2_cfg<T, 256, 128, 4, 2>(p, sp, stream);
             case 22: return launch_v2_cfg<T, 256, 256, 4, 2>(p, sp, stream);
             case 23: return launch_v2_cfg<T, 160, 320, 2, 4>(p, sp, stream);
-            case 24: return launch_v2_cfg<T, 160, 160, 2, 2>(p, sp, stream);
             case 25: return launch_v2_cfg<T, 128, 128, 2, 2>(p, sp, stream);
-            case 26: return launch_v2_cfg<T, 128, 64, 2, 2>(p, sp, stream);
             case 27: return launch_v2_cfg<T, 64, 128, 2, 2>(p, sp, stream);
             case 28: return launch_v2_cfg<T, 64, 64, 2, 2>(p, sp, stream);
-            case 29: return launch_v2_cfg<T, 128, 256, 2, 4>(p, sp, stream);
-            // 3 A-panel buffers (the A panel two slabs ahead): 31 = 256x128, 33 = 160x320, 34 = 160x160, 35 = 128x128, 39 = 128x256
-            case 31: return launch_v2_cfg<T, 256, 128, 4, 2, 3>(p, sp, stream);
-            case 33: return launch_v2_cfg<T, 160, 320, 2, 4, 3>(p, sp, stream);
-            case 34: return launch_v2_cfg<T, 160, 160, 2, 2, 3>(p, sp, stream);
-            case 35: return launch_v2_cfg<T, 128, 128, 2, 2, 3>(p, sp, stream);
-            case 39: return launch_v2_cfg<T, 128, 256, 2, 4, 3>(p, sp, stream);
         }
-#ifdef GEO4D_GEMM_ABLATION   // profiling build (make ABLATION=1): 40 + a = 160x320, 50 + a = 256x256, 60 + a = 128x128 with ablation a
-        if constexpr (IsX3<T>::value) {
-            if (p.w_split && !p.a_split) switch (p.tile_hint) {
-#define GEO4D_ABL(base, BM_, BN_, WM_, WN_)                                                        \
-                case base + 1: return launch_v2_kernel<T, BM_, BN_, WM_, WN_, 1, 2, 1>(p, sp, stream); \
-                case base + 2: return launch_v2_kernel<T, BM_, BN_, WM_, WN_, 1, 2, 2>(p, sp, stream); \
-                case base + 3: return launch_v2_kernel<T, BM_, BN_, WM_, WN_, 1, 2, 3>(p, sp, stream); \
-                case base + 4: return launch_v2_kernel<T, BM_, BN_, WM_, WN_, 1, 2, 4>(p, sp, stream);
-                GEO4D_ABL(40, 160, 320, 2, 4)
-                GEO4D_ABL(50, 256, 256, 4, 2)
-                GEO4D_ABL(60, 128, 128, 2, 2)
-#undef GEO4D_ABL
-            }
-        }
-#endif
         geo4d_set_error("conv_gemm: unknown tile_hint");
         return GEO4D_EINVAL;
     }

@@ -35,7 +35,6 @@ namespace geo4d_gemm {
 // the fall-back tiles live in the gemm_v2_*.hip translation units
 extern template int launch_v2_typed<bf16x3_t>(const geo4d_conv_gemm_t&, hipStream_t);
 extern template int launch_v2_typed<bf16_t>(const geo4d_conv_gemm_t&, hipStream_t);
-extern template int launch_v2_typed<f16_t>(const geo4d_conv_gemm_t&, hipStream_t);
 
 template <int BM, int BN>
 constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH; }
@@ -46,30 +45,14 @@ constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH; }
         __builtin_amdgcn_s_barrier();           \
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
-// the K loop's barrier / wait (ablation 7 / 6 drop them)
-#define GEO4D_V3_LBAR()                         \
-    do {                                        \
-        if constexpr (ABL != 7) GEO4D_V3_BAR(); \
-        else __builtin_amdgcn_sched_barrier(0); \
-    } while (0)
-#define GEO4D_V3_WAIT()                                                                          \
-    do {                                                                                         \
-        if constexpr (ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");   \
-    } while (0)
 
-// ABL (profiling builds only: make ABLATION=1, tile hints 80 + a / 90 + a; WRONG results by construction except 3 and 8):
-//   1 = no LDS-DMA inside the K loop   2 = no MFMA   3 = staggered wave groups (see STAG)   4 = WITH s_setprio around the MFMAs (correct results;
-//   the shipped lockstep kernel has none: -1..-4 % with it)
-//   5 = no fragment reads   6 = no DMA waits   9 = waves 4-7 issue their DMA pieces after the first third of the quadrant's MFMAs (correct results)
-//   7 = no barriers   8 = s_memtime stamps of waves 0 and 4 of workgroup 0 (4 per phase, slabs 8..23 of its first tile) -> p.workspace
-// STAG (ablation 3 only): the two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run staggered by one barrier, with a second
-// barrier inside every phase (issue / read | MFMA), so that one group's MFMA segment runs beside the other group's issue segment.
-// Measured 4-10 % SLOWER than all eight waves in lockstep with one barrier per phase (profiles/r03_gemm_v3_phased.md): the second
-// barrier costs more than the overlap returns.
-template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false, int ABL = 0, bool STAG = (ABL == 3)>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
+// (Round 3 also carried ablation builds of this loop - no DMA / no MFMA / no reads / no waits / no barriers / s_memtime stamps - a
+// variant with the two wave groups staggered by a second barrier per phase (4-10 % slower) and one with s_setprio around the MFMAs
+// (1-4 % slower in this lockstep schedule): profiles/r03_gemm_v3_phased.md has their numbers; round 4 removed them from the sources.)
+template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false>   // HOT: 0 generic, 1 raw A x split W, 2 split A x split W
 __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm_t p, const int splits, const int tiles_mn) {
     static_assert(WM * WN == 8, "two groups of four waves");
-    static_assert(!std::is_same<T, float>::value, "v3 serves the 16-bit MFMA forms (bf16, f16, bf16x3)");
+    static_assert(!std::is_same<T, float>::value, "v3 serves the 16-bit MFMA forms (bf16, bf16x3)");
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = BKC * EPC;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -90,7 +73,6 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int wr = wave / WN, wc = wave % WN;
-    const int grp = wave >> 2;                         // the second group runs one barrier behind the first
     const int tiles_n = (p.N + BN - 1) / BN;
     const int ntap = p.KT * p.KH * p.KW;
     const int hw = p.Hout * p.Wout;
@@ -334,23 +316,9 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     };
     // quadrant (HA, HB): term-major so that consecutive MFMAs write different accumulators; per accumulator the terms keep the order
     // of mma16_x3 (w.lo x a.hi, w.hi x a.lo, w.hi x a.hi; C rows = n, C cols = m) resp. K half 0, 1
-    auto mma_quadrant = [&](auto hac, auto hbc, auto mid) {
+    auto mma_quadrant = [&](auto hac, auto hbc) {
         constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
         constexpr int MBH = HA ? MB1 : MB0, NBH = HB ? NB1 : NB0, AO = HA ? MB0 : 0, BO = HB ? NB0 : 0;
-        if constexpr (ABL == 2) {                       // keep the fragments live, skip the matrix pipe
-#pragma unroll
-            for (int a = 0; a < MBH; ++a) asm volatile("" ::"v"(fa[HA][0][a]), "v"(fa[HA][1][a]));
-#pragma unroll
-            for (int b = 0; b < NBH; ++b) asm volatile("" ::"v"(fb[HB][0][b]), "v"(fb[HB][1][b]));
-            return;
-        }
-        if constexpr (ABL == 5) {                       // stale fragments: keep the registers opaque
-#pragma unroll
-            for (int a = 0; a < MBH; ++a) asm volatile("" : "+v"(fa[HA][0][a]), "+v"(fa[HA][1][a]));
-#pragma unroll
-            for (int b = 0; b < NBH; ++b) asm volatile("" : "+v"(fb[HB][0][b]), "+v"(fb[HB][1][b]));
-        }
-        if constexpr (STAG || ABL == 4) __builtin_amdgcn_s_setprio(1);     // only the staggered schedule has something to arbitrate
         if constexpr (IsX3<T>::value) {
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -364,7 +332,6 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
                                                                                       acc[AO + a][BO + b], 0, 0, 0);
                     }
                 }
-                if (term == 0) mid();
             }
         } else {
 #pragma unroll
@@ -374,24 +341,12 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
                     for (int a = 0; a < MBH; ++a) mma16<T>(acc[AO + a][BO + b], fb[HB][h][b], fa[HA][h][a]);
                 }
-                if (h == 0) mid();
             }
         }
-        if constexpr (STAG || ABL == 4) __builtin_amdgcn_s_setprio(0);
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
     const bool partial = splits > 1;                   // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
-    unsigned long long* tl = (unsigned long long*)(smem + 2 * STAGE);   // ABL 8: [group][slab 8..23][16 stamps]
-    bool first_tile = true;
-    auto stamp = [&](int t, int idx) {
-        if constexpr (ABL == 8) {
-            if (blockIdx.x == 0 && first_tile && (wave & 3) == 0 && t >= 8 && t < 24) {
-                const unsigned long long c = __builtin_amdgcn_s_memtime();
-                if (lane == 0) tl[(grp * 16 + (t - 8)) * 16 + idx] = c;
-            }
-        }
-    };
 
     // ---- first tile: windows, then the steady state's in-flight set A0(0) B0(0) B1(0) A1(0) A0(1) B1(1) B0(1) and the fragments of
     // the first quadrant ----------------------------------------------------------------------------------------------------------------
@@ -419,7 +374,6 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     __syncthreads();
     read_A(H0{}, smem);
     read_B(H0{}, smem);
-    if (grp == 1 && STAG) GEO4D_V3_BAR();
 
     while (true) {
 #pragma unroll
@@ -435,7 +389,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         //   phase 3: issue B_Y of slab c + 2                   | read B_Y of slab c + 1  | MFMA (A1, B_X)
         // Half panels are issued in the order they are read, FIVE phases ahead, and re-staged three phases after their read. The wait of
         // a phase retires the half panel the next phase reads: everything but the four half panels issued after it.
-        auto slab = [&](auto xc, int t) __attribute__((always_inline)) {
+        auto slab = [&](auto xc) __attribute__((always_inline)) {
             constexpr int X = decltype(xc)::value, Y = 1 - X;
             using HX = std::integral_constant<int, X>;
             using HY = std::integral_constant<int, Y>;
@@ -444,38 +398,30 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             auto phase = [&](auto jc, auto issue, auto read, auto split, auto mma, auto after) __attribute__((always_inline)) {
                 constexpr int J = decltype(jc)::value;
                 constexpr int NW = J == 2 ? 2 * (X ? CB1 : CB0) + CA1 + CA0 : NWAIT;
-                stamp(t, 4 * J);
-                if (ABL != 1 && (ABL != 9 || grp == 0)) issue();
-                if constexpr (ABL != 5) read();
-                if constexpr (STAG) {
-                    if constexpr (ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
-                    stamp(t, 4 * J + 1);
-                    GEO4D_V3_LBAR();
-                }
-                stamp(t, 4 * J + 2);
+                issue();
+                read();
                 split();
-                mma([&] { if (ABL == 9 && grp == 1) issue(); });
+                mma();
                 after();
-                if constexpr (!STAG && ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
-                stamp(t, 4 * J + 3);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
             };
             phase(std::integral_constant<int, 0>{}, [&] { issue_A(H1{}, Y); }, [&] { read_B(HY{}, sb); },
-                  [&] { split_A(H0{}); split_B(HX{}); }, [&](auto mid) { mma_quadrant(H0{}, HX{}, mid); }, [&] { advance_A(); });
-            GEO4D_V3_LBAR();
+                  [&] { split_A(H0{}); split_B(HX{}); }, [&] { mma_quadrant(H0{}, HX{}); }, [&] { advance_A(); });
+            GEO4D_V3_BAR();
             phase(std::integral_constant<int, 1>{}, [&] { issue_A(H0{}, X); }, [&] { read_A(H1{}, sb); },
-                  [&] { split_B(HY{}); }, [&](auto mid) { mma_quadrant(H0{}, HY{}, mid); }, [&] {});
-            GEO4D_V3_LBAR();
+                  [&] { split_B(HY{}); }, [&] { mma_quadrant(H0{}, HY{}); }, [&] {});
+            GEO4D_V3_BAR();
             phase(std::integral_constant<int, 2>{}, [&] { issue_B(HX{}, X); }, [&] { read_A(H0{}, so); },
-                  [&] { split_A(H1{}); }, [&](auto mid) { mma_quadrant(H1{}, HY{}, mid); }, [&] {});
-            GEO4D_V3_LBAR();
+                  [&] { split_A(H1{}); }, [&] { mma_quadrant(H1{}, HY{}); }, [&] {});
+            GEO4D_V3_BAR();
             phase(std::integral_constant<int, 3>{}, [&] { issue_B(HY{}, X); }, [&] { read_B(HY{}, so); },
-                  [&] {}, [&](auto mid) { mma_quadrant(H1{}, HX{}, mid); }, [&] { advance_B(); });
+                  [&] {}, [&] { mma_quadrant(H1{}, HX{}); }, [&] { advance_B(); });
         };
         for (int t = 0; t < ns; t += 2) {
-            slab(H0{}, t);
-            GEO4D_V3_LBAR();
-            slab(H1{}, t + 1);
-            if (t + 2 < ns) GEO4D_V3_LBAR();
+            slab(H0{});
+            GEO4D_V3_BAR();
+            slab(H1{});
+            if (t + 2 < ns) GEO4D_V3_BAR();
         }
         // the tile's closing barrier, then the epilogue; the next tile's first slabs are already in flight. (An epilogue placed on either
         // side of the barrier depending on the wave group made the register allocator spill ~900 VGPRs, with reloads - and their
@@ -490,25 +436,19 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         // a REAL s_waitcnt vmcnt(0) (the builtin, which the compiler's wait-count pass tracks; an inline-asm one it does not see):
         // without it the pass has to assume pending loads into VGPRs at the K loop's header and drains the DMA queue every slab
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        first_tile = false;
         if (!validS) break;                            // the staging tile is the next tile of the MFMAs
         tmC = tmS; tnC = tnS; kzC = kzS; bzC = bzS;
     }
-    if (grp == 0 && STAG) GEO4D_V3_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy pieces of the stream's tail must land before the LDS is released
-    if constexpr (ABL == 8) {
-        __syncthreads();
-        if (blockIdx.x == 0 && p.workspace) ((unsigned long long*)p.workspace)[tid] = tl[tid];    // 2 x 16 x 16 stamps
-    }
 }
 
 // one workgroup per CU (96-155 KB of LDS); persistent over the tile list
-template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false, int ABL = 0>
+template <typename T, int BM, int BN, int WM, int WN, int HOT, bool OSPLIT = false>
 int launch_v3_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
-    constexpr int smem = v3_smem_bytes<BM, BN>() + (ABL == 8 ? 4096 : 0);
+    constexpr int smem = v3_smem_bytes<BM, BN>();
     static_assert(smem <= 160 * 1024, "LDS");
     static int resident = 0;
-    auto kern = conv_gemm_v3_kernel<T, BM, BN, WM, WN, HOT, OSPLIT, ABL>;
+    auto kern = conv_gemm_v3_kernel<T, BM, BN, WM, WN, HOT, OSPLIT>;
     if (!resident) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             geo4d_set_error("hipFuncSetAttribute(max dynamic LDS) failed");
@@ -545,10 +485,8 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
     if constexpr (IsX3<T>::value) {
         if (p.o_split) {
-            if constexpr ((BN / WN / 16) % 4 == 0) {
-                if (p.act == 2 && p.w_split && p.a_split) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
-            }
-            geo4d_set_error("conv_gemm: o_split is built for the GEGLU epilogue (act 2) of pre-split x pre-split launches on GEGLU-capable tiles");
+            if (o_split_ok(p, splits)) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+            geo4d_set_error("conv_gemm: o_split needs pre-split x pre-split operands, no split-K, N % 8 == 0 and 32-byte aligned output rows");
             return GEO4D_EINVAL;
         }
         if (p.w_split && !p.a_split) return launch_v3_kernel<T, BM, BN, WM, WN, 1>(p, splits, stream);
@@ -564,11 +502,11 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 // nearest-upsampling gathers, operands beyond the 2 GB buffer window) fall back to the second-generation tile of the same shape.
 template <typename T>
 int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
-    if constexpr (std::is_same<T, float>::value) {
-        geo4d_set_error("conv_gemm: tile hints 71..74 serve bf16 / f16 / bf16x3 (the exact-f32 mode stays on hints 0..17)");
+    if constexpr (std::is_same<T, float>::value || std::is_same<T, f16_t>::value) {
+        geo4d_set_error("conv_gemm: tile hints 71..74 serve bf16 / bf16x3 (the exact-f32 and the f16 modes stay on hints 0..17)");
         return GEO4D_EINVAL;
     } else {
-        if (p.out_nchw || p.gn_colsum || p.debug_ablate == 1) {
+        if (p.out_nchw || p.gn_colsum) {
             geo4d_set_error("conv_gemm: tile hints 71..74 have no NCTHW / gn_colsum epilogue");
             return GEO4D_EINVAL;
         }
@@ -581,25 +519,6 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             }
             sp = p.split_k;
         }
-#ifdef GEO4D_GEMM_ABLATION   // profiling build (make ABLATION=1): 80 + a = 160x320, 90 + a = 192x256 with ablation a, pre-split x pre-split bf16x3 only
-        if constexpr (IsX3<T>::value) {
-            if (p.w_split && p.a_split && !p.o_split) switch (p.tile_hint) {
-#define GEO4D_ABL3(base, BM_, BN_)                                                                        \
-                case base + 1: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 1>(p, sp, stream); \
-                case base + 2: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 2>(p, sp, stream); \
-                case base + 3: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 3>(p, sp, stream); \
-                case base + 4: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 4>(p, sp, stream); \
-                case base + 5: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 5>(p, sp, stream); \
-                case base + 9: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 9>(p, sp, stream); \
-                case base + 6: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 6>(p, sp, stream); \
-                case base + 7: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 7>(p, sp, stream); \
-                case base + 8: return launch_v3_kernel<T, BM_, BN_, 2, 4, 2, false, 8>(p, sp, stream);
-                GEO4D_ABL3(80, 160, 320)
-                GEO4D_ABL3(90, 192, 256)
-#undef GEO4D_ABL3
-            }
-        }
-#endif
         if (p.tile_hint < 71 || p.tile_hint > 74) {
             geo4d_set_error("conv_gemm: unknown tile_hint");
             return GEO4D_EINVAL;
@@ -622,7 +541,7 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
         const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
         if (nslab % sp || ((nslab / sp) & 1) || nslab / sp < 4 || !vec_ok || !window_ok) {
             geo4d_conv_gemm_t q = p;
-            q.tile_hint = p.tile_hint == 71 ? 22 : p.tile_hint == 72 ? 23 : p.tile_hint == 73 ? 21 : 29;
+            q.tile_hint = p.tile_hint == 71 ? 22 : p.tile_hint == 72 ? 23 : 25;      // (every tile sums in the same order: same bits)
             return launch_v2_typed<T>(q, stream);
         }
         switch (p.tile_hint) {
@@ -636,7 +555,5 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
 }
 
 #undef GEO4D_V3_BAR
-#undef GEO4D_V3_LBAR
-#undef GEO4D_V3_WAIT
 
 }  // namespace geo4d_gemm

@@ -14,11 +14,16 @@
 
 namespace {
 
-__host__ __device__ inline int gn_rows_per_chunk(int HW) {
-    int r = HW / 64;
-    if (r < 32) r = 32;
+// rows of one frame per workgroup of the statistics / apply launches. Round 4: sized so that a launch has ~1024 workgroups whatever the
+// level - the former HW / 64 with a floor of 32 rows left the 10x16 and 5x8 levels of the U-Net with 80 and 32 workgroups on 256 CUs
+// (their three launches cost ~10 us each: 86 of the 166 GroupNorms of a forward, profiles/r04_groupnorm_chunks.md); a multiple of 4
+// rows (the 4 loads in flight per lane), at most 1024.
+__host__ __device__ inline int gn_rows_per_chunk(int HW, int F) {
+    long r = ((long)HW * F + 1023) / 1024;
+    r = (r + 3) / 4 * 4;
+    if (r < 4) r = 4;
     if (r > 1024) r = 1024;
-    return r;
+    return (int)r;
 }
 
 // ---- GroupNorm pass 1: per (frame, row-chunk, group) partial (n, mean, M2) ----------------
@@ -109,7 +114,7 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
         n = nn;
     }
 }
-// one wave merges the fps * nchunk partials of (stat, grp); lane 0 returns (mean, rstd). Same order in the 3-launch and the fused path.
+// one wave merges the fps * nchunk partials of (stat, grp); lane 0 returns (mean, rstd)
 __device__ __forceinline__ f32x2 gn_merge_unit(const float* __restrict__ part, int total, int stat, int grp, int G, float eps, int lane) {
     float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int i = lane; i < total; i += 64) {
@@ -137,41 +142,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     if (lane == 0) {
         stats[((long)stat * G + grp) * 2 + 0] = r[0];
         stats[((long)stat * G + grp) * 2 + 1] = r[1];
-    }
-}
-
-// ---- GroupNorm pass 1 + 2 in ONE launch: every workgroup writes its partial, takes a ticket on its statistic's counter, and the LAST
-// arriver of a statistic (frames_per_stat x nchunk tickets) merges that statistic's partials - the same fixed-order merge as
-// gn_finalize_kernel, so the result is bit-identical - and clears the counter for the next GroupNorm. Nobody waits (no co-residency
-// requirement, unlike a grid barrier): release before the ticket, acquire in the last arriver (cdna_hip_programming.md Guideline 16).
-template <typename T>
-__global__ __launch_bounds__(256) void gn_partial_last_kernel(const T* __restrict__ x, long ldx, int HW, int C, int G, int R, int nchunk,
-                                                              int fps, float eps, float* __restrict__ part, float* __restrict__ stats,
-                                                              unsigned int* __restrict__ counters) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int is_last;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f = blockIdx.y, stat = f / fps;
-    gn_partial_body<T>(smem, x, ldx, HW, C, G, R, nchunk, part, blockIdx.x, f);
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int ticket = __hip_atomic_fetch_add(counters + stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = ticket == (unsigned int)(fps * nchunk - 1);
-        if (is_last) {
-            __hip_atomic_store(counters + stat, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-    }
-    __syncthreads();
-    if (!is_last) return;
-    for (int grp = wave; grp < G; grp += 4) {
-        const f32x2 r = gn_merge_unit(part, fps * nchunk, stat, grp, G, eps, lane);
-        if (lane == 0) {
-            stats[((long)stat * G + grp) * 2 + 0] = r[0];
-            stats[((long)stat * G + grp) * 2 + 1] = r[1];
-        }
     }
 }
 
@@ -274,56 +244,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     gn_apply_body<T, SPLIT>(x, ldx, y, ldy, HW, C, G, R, stats + (long)(f / fps) * G * 2, gamma, beta, act, blockIdx.x, f);
 }
 
-// ---- GroupNorm in ONE launch: statistics pass, grid-wide barrier, merge of this frame's partials, apply pass -------------------
-// Every workgroup owns the same (row chunk, frame) in both passes, so the second read of x comes from its XCD's L2 / the Infinity
-// Cache instead of HBM for the U-Net's tensors, and the 166 GroupNorms of a forward cost 166 launches instead of 498.
-// The barrier is a self-resetting counter + generation pair in a persistent, zero-initialised device buffer (stream-ordered use:
-// one GroupNorm at a time per buffer): a workgroup reads the generation BEFORE it arrives, the last arriver clears the counter and
-// bumps the generation. Release / acquire at agent scope around it (cdna_hip_programming.md Guideline 16). The host only takes this
-// path when all workgroups are co-resident; a spin budget turns a scheduling accident into a trap instead of a hung GPU.
-// Results are bit-identical to the three-launch path (same partials, same merge order).
-template <typename T, bool SPLIT>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int HW, int C, int G,
-                                                       int fps, int R, int nchunk, float eps, float* __restrict__ part,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                       unsigned int* __restrict__ bar) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float st[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.x, f = blockIdx.y;
-    unsigned int gen0 = 0;
-    if (tid == 0) gen0 = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gn_partial_body<T>(smem, x, ldx, HW, C, G, R, nchunk, part, chunk, f);
-    __syncthreads();                                   // this workgroup's partial (written by threads < G) is issued
-    if (tid == 0) {
-        const unsigned int nwg = gridDim.x * gridDim.y;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int old = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == nwg - 1) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            long spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1L << 22)) __builtin_trap();       // ~seconds: not co-resident after all - fail loudly, never hang
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    const int stat = f / fps;
-    for (int grp = wave; grp < G; grp += 4) {              // one wave per group, fixed order inside (same as gn_finalize_kernel)
-        const f32x2 r = gn_merge_unit(part, fps * nchunk, stat, grp, G, eps, lane);
-        if (lane == 0) { st[grp * 2] = r[0]; st[grp * 2 + 1] = r[1]; }
-    }
-    __syncthreads();
-    gn_apply_body<T, SPLIT>(x, ldx, y, ldy, HW, C, G, R, st, gamma, beta, act, chunk, f);
-}
-
 // ---- LayerNorm: one wave per row, row held in registers ------------------------------------
 template <typename T, int MAXC, bool SPLIT = false>  // MAXC = chunks per lane; SPLIT (f32 only): write the pre-split bf16x3 operand format
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int M, int C,
@@ -403,61 +323,26 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = tid; c < cols; c += 256) Elem<T>::st(yr + c, __expf(xr[c] * scale - m) * inv);
 }
 
-// workgroups of gn_fused_kernel<T, SPLIT> that are resident at once (CUs x occupancy), cached per instantiation
-template <typename T, bool SPLIT>
-int gn_fused_capacity(size_t smem) {
-    static int cap = 0;
-    if (!cap) {
-        int dev = 0, cus = 0, occ = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gn_fused_kernel<T, SPLIT>, 256, smem) != hipSuccess) return 0;
-        cap = cus * occ;
-    }
-    return cap;
-}
-
 template <typename T, bool SPLIT>
 int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     constexpr int EPC = Elem<T>::EPC;
-    int R = gn_rows_per_chunk(p.HW);
+    int R = gn_rows_per_chunk(p.HW, p.F);
     int nchunk = (p.HW + R - 1) / R;
     float* part = (float*)p.workspace;
     const size_t smem = (size_t)256 * 2 * EPC * 4 + (size_t)2 * p.C * 4;
     const int nstat = p.F / p.frames_per_stat;
-    if (p.barrier && !p.colsum) {
-        // one launch when every workgroup can be resident (the grid-wide barrier needs that); larger tensors take fewer, longer chunks
-        int cap = gn_fused_capacity<T, SPLIT>(smem);
-        if (cap > 2048) cap = 2048;
-        if (cap >= p.F) {
-            if ((long)nchunk * p.F > cap) {
-                const int per_frame = cap / p.F;
-                R = ((p.HW + per_frame - 1) / per_frame + 7) / 8 * 8;
-                nchunk = (p.HW + R - 1) / R;
-            }
-            hipLaunchKernelGGL((gn_fused_kernel<T, SPLIT>), dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy,
-                               p.HW, p.C, p.groups, p.frames_per_stat, R, nchunk, p.eps, part, p.gamma, p.beta, p.act, (unsigned int*)p.barrier);
-            GEO4D_CHECK_LAUNCH();
-            return GEO4D_OK;
-        }
-    }
     float* stats = part + (size_t)p.F * nchunk * p.groups * 3;
     if (p.colsum) {     // statistics already summed per 32-row block by the producing GEMM's epilogue: no pass over x
         hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nstat * p.groups), dim3(256), 0, s, p.colsum, p.frames_per_stat * (p.HW / 32),
                            p.C, p.groups, p.eps, stats, nstat);
         GEO4D_CHECK_LAUNCH();
     } else {
-        if (p.counters && nstat <= 1024) {       // statistics + merge by the last arriver: two launches per GroupNorm instead of three
-            hipLaunchKernelGGL(gn_partial_last_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
-                               R, nchunk, p.frames_per_stat, p.eps, part, stats, (unsigned int*)p.counters);
-            GEO4D_CHECK_LAUNCH();
-        } else {
-            hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
-                               R, nchunk, part);
-            GEO4D_CHECK_LAUNCH();
-            hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
-                               p.groups, p.eps, stats, nstat);
-            GEO4D_CHECK_LAUNCH();
-        }
+        hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
+                           R, nchunk, part);
+        GEO4D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat * p.groups + 3) / 4), dim3(256), 0, s, part, nchunk, p.frames_per_stat,
+                           p.groups, p.eps, stats, nstat);
+        GEO4D_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL((gn_apply_kernel<T, SPLIT>), dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
                        p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act);
@@ -486,7 +371,7 @@ int layernorm_typed(const void* x, long ldx, void* y, long ldy, int M, int C, fl
 }  // namespace
 
 extern "C" size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat) {
-    const int R = gn_rows_per_chunk(HW);
+    const int R = gn_rows_per_chunk(HW, F);
     const int nchunk = (HW + R - 1) / R;
     return ((size_t)F * nchunk * groups * 3 + (size_t)(F / frames_per_stat) * groups * 2) * sizeof(float);
 }
@@ -506,8 +391,6 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
     if (p.F > 65535) { geo4d_set_error("groupnorm: too many frames"); return GEO4D_EINVAL; }
     if (p.colsum && ((p.HW % 32) || ((uintptr_t)p.colsum % 8))) { geo4d_set_error("groupnorm: colsum needs HW % 32 == 0"); return GEO4D_EINVAL; }
     if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8))) { geo4d_set_error("groupnorm: split_out is the bf16x3 producer format: f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
-    if (p.barrier && ((uintptr_t)p.barrier % 8)) { geo4d_set_error("groupnorm: barrier alignment"); return GEO4D_EINVAL; }
-    if (p.counters && ((uintptr_t)p.counters % 4)) { geo4d_set_error("groupnorm: counters alignment"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {
         case GEO4D_F32: return p.split_out ? groupnorm_typed<float, true>(p, s) : groupnorm_typed<float, false>(p, s);

@@ -2,6 +2,7 @@
 
 None of these are on the Geo4D inference path (the entry scripts never import ``dust3r.inference``); the north-star asks
 for the names to exist. They are plain-PyTorch host utilities with the reference signatures — no kernels, no hot path.
+`inference()` is the reference's batching loop over a CALLER-SUPPLIED pairwise model (round 4; tests/test_dust3r_inference_cpu.py).
 """
 import torch
 
@@ -46,11 +47,68 @@ def loss_of_one_batch(batch, model, criterion, device, symmetrize_batch=False, u
     return result[ret] if ret else result
 
 
+def to_cpu(x):
+    """dust3r/utils/device.py:10-44 (`todevice(x, 'cpu')`): every tensor of a nested dict / list / tuple moved to the host, numpy arrays
+    become tensors, containers keep their type, everything else passes through."""
+    import numpy as np
+    if isinstance(x, dict):
+        return {k: to_cpu(v) for k, v in x.items()}
+    if isinstance(x, (tuple, list)):
+        return type(x)(to_cpu(v) for v in x)
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.to("cpu") if torch.is_tensor(x) else x
+
+
+def collate_with_cat(items, lists=False):
+    """dust3r/utils/device.py:47-75: merge a list of per-batch results into one. Dicts are merged key by key and tuples position by
+    position (recursively); tensors / arrays are concatenated along dim 0, or flattened into one python list of samples when `lists`
+    (images of different sizes cannot be stacked); scalars / strings stay the list they are; nested lists are chained; a list that
+    starts with None collapses to None."""
+    import numpy as np
+    if isinstance(items, dict):
+        return {k: collate_with_cat(v, lists=lists) for k, v in items.items()}
+    if not isinstance(items, (tuple, list)):
+        return items
+    if len(items) == 0:
+        return items
+    first, kind = items[0], type(items)
+    if first is None:
+        return None
+    if isinstance(first, (bool, int, float, str)):
+        return items
+    if isinstance(first, tuple):
+        return kind(collate_with_cat(col, lists=lists) for col in zip(*items))
+    if isinstance(first, dict):
+        return {k: collate_with_cat([it[k] for it in items], lists=lists) for k in first}
+    if isinstance(first, (torch.Tensor, np.ndarray)):
+        if lists:
+            return [sample for batch in items for sample in batch]
+        return torch.cat([torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in items])
+    out = kind()
+    for it in items:              # lists of lists: chain
+        out = out + it
+    return out
+
+
 @torch.no_grad()
 def inference(pairs, model, device, batch_size=8, verbose=True):
-    """dust3r/inference.py:82-101."""
-    raise NotImplementedError("dust3r pairwise inference needs the DUSt3R/CroCo network, which Geo4D does not ship "
-                              "(dust3r/model.py imports the un-vendored `croco`); kept as a named entry point only")
+    """dust3r/inference.py:82-101: run a pairwise model (any callable `model(view1, view2) -> (pred1, pred2)`; the reference passes its
+    DUSt3R network, which Geo4D does not ship) over `pairs` = [(view1_dict, view2_dict), ...] in batches: collate the pairs of a batch,
+    call the model through loss_of_one_batch (no criterion), bring the result to the host, and collate the per-batch results into one
+    dict(view1, view2, pred1, pred2, loss). Pairs whose images differ in size force batch size 1 and list-valued (unstacked) outputs."""
+    if verbose:
+        print(f">> Inference with model on {len(pairs)} image pairs")
+    ragged = not check_if_same_size(pairs)
+    if ragged:
+        batch_size = 1
+    chunks = []
+    for lo in range(0, len(pairs), batch_size):
+        out = loss_of_one_batch(collate_with_cat(pairs[lo:lo + batch_size]), model, None, device)
+        chunks.append(to_cpu(out))
+        if verbose:
+            print(f"   pairs {lo}..{min(lo + batch_size, len(pairs)) - 1} done")
+    return collate_with_cat(chunks, lists=ragged)
 
 
 def get_pred_pts3d(gt, pred, use_pose=False):

@@ -37,8 +37,9 @@ def is_split(w, other):
 class SplitAct(torch.Tensor):
     """A bf16 [rows, 2K] activation in the pre-split bf16x3 operand format (per 8 K-elements: 8 x bf16 hi | 8 x bf16 lo), written by
     the producers that feed GEMMs (GroupNorm / LayerNorm / attention / GEGLU epilogue with split_out) so that conv_gemm does not
-    split the fragments again in its K loop. A Tensor subclass only to make the format visible to conv_gemm (and to fail loudly if
-    such a buffer reaches a kernel that expects plain f32)."""
+    split the fragments again in its K loop. A Tensor subclass only to make the format visible to conv_gemm; every other entry point
+    of this module rejects it (`_dev`), and producers require a whole contiguous matrix as their split output (`_split_out_ok`).
+    Plain torch ops on it (.float(), slicing at non-8-element offsets) still see a bf16 matrix: do not use them."""
     @staticmethod
     def wrap(t):
         return t.as_subclass(SplitAct)
@@ -62,11 +63,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _dev(t, what):
+def _dev(t, what, split_ok=False):
+    """Every operand goes through here: it must live on a HIP device, and a SplitAct (bf16 [rows, 2K] hi | lo image) may only reach
+    the operands that understand the format - conv_gemm's A / W / out and the producers' `out`; anywhere else it would be silently
+    reinterpreted as a bf16 matrix."""
     if not t.is_cuda:
         raise _lib.Geo4DNativeError(f"geo4d_amd.ops: `{what}` lives on {t.device}; the HIP path needs a GPU tensor "
                                     "(there is no CPU fallback)")
+    if isinstance(t, SplitAct) and not split_ok:
+        raise TypeError(f"geo4d_amd.ops: `{what}` is a pre-split bf16x3 activation (SplitAct); only GEMM operands take that format")
     return t
+
+
+def _split_out_ok(out, rows):
+    """Producers write the pre-split format with row-start-relative addressing (store_split4): the buffer must be the whole
+    [rows, 2K] matrix - contiguous, starting at the row, 16-byte aligned - not a column-offset view of a wider one."""
+    assert out.dim() == 2 and out.shape[0] == rows and out.is_contiguous() and out.data_ptr() % 16 == 0, \
+        "a SplitAct output must be a contiguous [rows, 2K] matrix (no column-offset views)"
 
 
 def _ptr(t):
@@ -82,7 +95,7 @@ _WS = {}
 WORKSPACE_BYTES = 256 << 20
 
 # ---- per-shape launch tuning ------------------------------------------------------------------------------------
-# geo4d_conv_gemm has 5 four-wave tile shapes + the 8-wave 256x128 / 256x256 tiles (hints 11, 13) x split-K factors; the C-side heuristic is a fallback. The host keeps a table
+# geo4d_conv_gemm has three kernel generations x tile shapes x split-K factors (include/geo4d_hip.h tile_hint); the C-side heuristic is a fallback. The host keeps a table
 # problem-signature -> (tile_hint, split_k): loaded from geo4d_amd/tuning/gfx950.json (measured on MI355X by
 # tools/tune_gemm.py) and, for shapes not in it, filled by timing the candidates on first eager use (never while a
 # hipGraph is being captured). Every candidate computes the same sums in the same k order per output element
@@ -93,21 +106,23 @@ import os as _os
 _TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950.json")
 _TUNE = None
 _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1), (17, 2), (16, 2), (17, 8), (1, 2), (1, 4), (1, 8), (11, 2), (11, 8), (13, 2), (13, 4), (3, 2), (4, 2), (4, 4), (3, 4), (2, 4), (5, 1),
-               # round 3 (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups; refused for f32 / NCTHW outputs)
-               (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (21, 2), (21, 4), (21, 8), (22, 2), (22, 4),
-               (23, 2), (24, 2), (24, 4), (25, 2), (25, 4), (25, 8), (26, 2), (26, 4), (27, 2), (27, 4), (28, 2), (28, 4), (28, 8), (29, 2),
-               (31, 1), (33, 1), (34, 1), (35, 1), (39, 1), (31, 2), (31, 4), (31, 8), (33, 2), (33, 4), (34, 2), (34, 4), (35, 2), (35, 4), (35, 8),
-               # round 3 (gemm_kernel_v3.h: phased K loop, counted DMA waits, staggered wave groups; 8-wave tiles, one workgroup per CU).
+               # second generation (gemm_kernel_v2.h: 16x16x32 MFMA, register epilogue, persistent workgroups; bf16 / bf16x3, no NCTHW outputs);
+               # round 4 kept the five tiles the measured table selects
+               (22, 1), (23, 1), (25, 1), (27, 1), (28, 1), (22, 2), (22, 4), (23, 2), (25, 2), (25, 4), (25, 8), (27, 2), (27, 4), (28, 2), (28, 4), (28, 8),
+               # third generation (gemm_kernel_v3.h: phased K loop, counted DMA waits; 8-wave tiles, one workgroup per CU).
                # Splits that do not divide the K slabs evenly run on the second-generation twin inside the library.
                (71, 1), (72, 1), (73, 1), (74, 1), (71, 2), (72, 2), (73, 2), (74, 2), (71, 3), (72, 3), (73, 3), (74, 3), (71, 4), (73, 4), (74, 4),
                (71, 5), (73, 5), (74, 5), (73, 6), (74, 6), (73, 8), (74, 8), (73, 10), (74, 10)]
+_VALID_HINTS = {t for t, _ in _CANDIDATES} | {0}
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
 # GEMM epilogues can emit the next GroupNorm's column sums (gn_stats=True call sites). OFF by default: measured on MI355X the fused
 # path is correct but not faster yet (round 2: -3.5 % bf16x3, -7 % bf16 with the first finalize kernel) - the epilogue work lands on
 # every producing GEMM while the 5-D GroupNorms' merge over 12800 items per group is latency-bound; kept behind the switch for A/B.
 GN_FUSED_STATS = _os.environ.get("GEO4D_GN_FUSED", "0") != "0"
+TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) of every shape autotuned in this process (tools/tune_gemm.py prints it)
 DEBUG_ABLATE = 0       # tools/gemm_bench.py --ablate only
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
+ATTN_TIMELINE = None   # the same for the spatial self-attention launches (one key/value set) of ops.attention
 
 
 def _tune_table():
@@ -116,7 +131,7 @@ def _tune_table():
         _TUNE = {}
         if _os.path.exists(_TUNE_PATH):
             with open(_TUNE_PATH) as f:
-                _TUNE = {k: tuple(v) for k, v in _json.load(f).items()}
+                _TUNE = {k: tuple(v) for k, v in _json.load(f).items() if v[0] in _VALID_HINTS}     # (entries naming a retired tile hint are re-tuned)
     return _TUNE
 
 
@@ -125,23 +140,40 @@ def save_tuning(path=None):
         _json.dump({k: list(v) for k, v in sorted(_tune_table().items())}, f, indent=0)
 
 
-def _autotune(launch, key):
-    best, best_t = (0, 0), float("inf")
+def _time_launches(launch, tile, split, n):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        launch(tile, split)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def _autotune(launch, key):
+    """Two stages (round 4: a single 3-launch sample per candidate mis-ranked candidates that differ by 30-40 % when re-measured in
+    isolation, profiles/r04_gemm_retune.md): (1) every candidate, 4 launches after a warm-up; (2) the 6 fastest re-measured in three
+    interleaved rounds of 12 launches, ranked by their best round (the chip's clock moves under load: the minimum is the least noisy
+    estimate of what a launch costs inside a replayed graph)."""
+    stage1 = []
     for tile, split in _CANDIDATES:
         try:
             launch(tile, split)
         except RuntimeError:
             continue
-        e0.record()
-        for _ in range(3):
-            launch(tile, split)
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1)
-        if t < best_t:
-            best, best_t = (tile, split), t
+        stage1.append((_time_launches(launch, tile, split, 4), tile, split))
+    if not stage1:
+        _tune_table()[key] = (0, 0)
+        return (0, 0)
+    stage1.sort()
+    finalists = stage1[:6]
+    best_of = {(t, s): float("inf") for _, t, s in finalists}
+    for _ in range(3):
+        for _, tile, split in finalists:
+            best_of[(tile, split)] = min(best_of[(tile, split)], _time_launches(launch, tile, split, 12))
+    best = min(best_of, key=best_of.get)
     _tune_table()[key] = best
+    TUNE_LOG.append((key, best, best_of[best], [(t, s, round(v * 1e3, 1)) for (t, s), v in sorted(best_of.items(), key=lambda kv: kv[1])]))
     return best
 
 
@@ -151,7 +183,6 @@ def workspace(device):
     if ws is None:
         ws = _WS[device] = (torch.empty(WORKSPACE_BYTES, device=device, dtype=torch.uint8),
                             torch.zeros(256, device=device, dtype=torch.uint8))
-        gn_barrier(device)      # allocated with the other persistent scratch, i.e. never inside a graph capture
     return ws
 
 
@@ -162,7 +193,12 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     """`lda` / `ldw` / `a_bs` / `w_bs` are strides of the tensors as passed (torch elements). bf16x3 mode is selected by the
     operands: f32 activations against a pre-split bf16 weight (either side), or two f32 operands with `x3=True`."""
     lib = _lib.load()
-    _dev(a, "A"); _dev(w, "W"); _dev(out, "out")
+    _dev(a, "A", True); _dev(w, "W", True); _dev(out, "out", True)
+    for opt, nm in ((bias, "bias"), (rowbias, "rowbias"), (residual, "residual")):
+        if opt is not None:
+            _dev(opt, nm)
+    if isinstance(out, SplitAct) and batch == 1:
+        _split_out_ok(out, M)
     a_split, w_split = is_split(a, w), is_split(w, a)
     if isinstance(a, SplitAct) or isinstance(w, SplitAct):     # pre-split activations x pre-split weights (bf16 storage, 4 bytes per K element)
         assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and lda % 2 == 0 and ldw % 2 == 0 and a_bs % 2 == 0 and w_bs % 2 == 0
@@ -318,20 +354,6 @@ def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias
 _gn_ws = {}
 
 
-GN_ONE_LAUNCH = _os.environ.get("GEO4D_GN_ONE_LAUNCH", "0") != "0"   # statistics + merge + apply around a grid-wide barrier (norm.hip)
-GN_TWO_LAUNCH = _os.environ.get("GEO4D_GN_TWO_LAUNCH", "0") != "0"   # statistics launch whose last-arriving workgroup merges (measured slower: per-workgroup agent-scope release)
-_gn_barrier = {}
-
-
-def gn_barrier(device):
-    """8 zero bytes per device for the one-launch GroupNorm's grid barrier (self-resetting; GroupNorms are stream-ordered).
-    Allocated on first use outside graph capture (callers warm up eagerly before capturing)."""
-    b = _gn_barrier.get(device)
-    if b is None:
-        b = _gn_barrier[device] = torch.zeros(2 + 1024, device=device, dtype=torch.int32)     # barrier pair + 1024 ticket counters
-    return b
-
-
 def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=False, out=None, split_out=False):
     """`split_out` (f32 input of the bf16x3 mode): y is returned as a SplitAct, the pre-split A operand of the conv that follows."""
     lib = _lib.load()
@@ -343,6 +365,8 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     if out is None:
         out = new_split(F * HW, Cc, x.device) if split_out else torch.empty((F * HW, Cc), device=x.device, dtype=x.dtype)
     split_out = isinstance(out, SplitAct)
+    if split_out:
+        _split_out_ok(out, F * HW)
     need = lib.geo4d_groupnorm_workspace(F, HW, groups, frames_per_stat)
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     p = GroupNorm()
@@ -350,8 +374,6 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     p.workspace, p.workspace_bytes = ws.data_ptr(), need
     p.ldx, p.ldy = _ld(x), (_ld(out) // 2 if split_out else _ld(out))
     p.split_out = int(split_out)
-    p.barrier = gn_barrier(x.device).data_ptr() if GN_ONE_LAUNCH else 0
-    p.counters = gn_barrier(x.device).data_ptr() + 8 if GN_TWO_LAUNCH else 0
     p.F, p.HW, p.C, p.groups, p.frames_per_stat = F, HW, Cc, groups, frames_per_stat
     p.act, p.dtype, p.eps = int(silu), dt_code(x.dtype), eps
     cs = getattr(x, "_gn_colsum", None)     # column sums left on this very tensor object by the GEMM that produced it
@@ -371,6 +393,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, split_out=False):
         assert x.dtype == torch.float32
         if out is None:
             out = new_split(M, Cc, x.device)
+        _split_out_ok(out, M)
         _lib.check(lib.geo4d_layernorm_split(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out) // 2, M, Cc, eps, gamma.data_ptr(),
                                              beta.data_ptr(), _stream()), "geo4d_layernorm_split")
         return out
@@ -402,20 +425,28 @@ def softmax_rows(x, scale, out_dtype, out=None, causal_period=0):
 ATTN_VARIANT = int(_os.environ.get("GEO4D_ATTN_VARIANT", "0"))   # 0 = library default; 1..3 = A/B builds (include/geo4d_hip.h)
 
 
-def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False, variant=None, split_out=False):
+def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False, variant=None, split_out=False, qkv_split=False):
     """q [B*Nq, >=H*64] view; kv = list of (k, vt, Nk, kv_div, vt_bs): k [(B/kv_div)*Nk, >=H*64] view, vt = V TRANSPOSED
-    as a [>=H*64, ld] view (row = channel, column = key) whose batch b' starts vt_bs elements after batch b'-1."""
+    as a [>=H*64, ld] view (row = channel, column = key) whose batch b' starts vt_bs elements after batch b'-1.
+    `qkv_split` (bf16x3, one key/value set): q, k and vt are SplitAct views (bf16, 2 per element: what the projections wrote with
+    split_out=True), strides / vt_bs in bf16 elements as torch reports them."""
     lib = _lib.load()
+    if qkv_split:
+        assert len(kv) == 1 and all(isinstance(t, SplitAct) for t in (q, kv[0][0], kv[0][1])), "qkv_split takes SplitAct q / k / vt of one key/value set"
+        return _attention_presplit(lib, q, kv[0], B=B, H=H, Nq=Nq, scale=scale, out=out, variant=variant, split_out=split_out)
     _dev(q, "q")
     if out is None:
         out = new_split(B * Nq, H * 64, q.device) if split_out else torch.empty((B * Nq, H * 64), device=q.device, dtype=q.dtype)
     split_out = isinstance(out, SplitAct)
+    if split_out:
+        _split_out_ok(out, B * Nq)
     p = Attention()
     p.q, p.o, p.ldq, p.ldo = q.data_ptr(), out.data_ptr(), _ld(q), (_ld(out) // 2 if split_out else _ld(out))
     p.split_out = int(split_out)
     assert 1 <= len(kv) <= 2
     for i, (k, vt, nk, div, vt_bs) in enumerate(kv):
         assert k.dtype == q.dtype and vt.dtype == q.dtype
+        _dev(k, "k"); _dev(vt, "vt")
         p.k[i], p.vt[i], p.ldk[i], p.ldvt[i], p.vt_bs[i], p.Nk[i], p.kv_div[i] = k.data_ptr(), vt.data_ptr(), _ld(k), _ld(vt), vt_bs, nk, div
     p.zeros = workspace(q.device)[1].data_ptr()
     code = dt_code(q.dtype)
@@ -424,14 +455,55 @@ def attention(q, kv, *, B, H, Nq, scale, out=None, x3=False, variant=None, split
         code = BF16X3
     p.B, p.H, p.Nq, p.nseg, p.head_dim, p.dtype, p.scale = B, H, Nq, len(kv), 64, code, scale
     p.variant = ATTN_VARIANT if variant is None else variant
-    _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
+    _launch_attention(lib, p)
     return out
 
 
-def linear_t_batched(w, x, batch, rows, dtype_align=None):
+def _attention_presplit(lib, q, kv0, *, B, H, Nq, scale, out, variant, split_out):
+    k, vt, nk, div, vt_bs = kv0
+    for t, nm in ((q, "q"), (k, "k"), (vt, "vt")):
+        _dev(t, nm, True)
+        assert t.dtype == torch.bfloat16 and _ld(t) % 2 == 0
+    if out is None:
+        out = new_split(B * Nq, H * 64, q.device) if split_out else torch.empty((B * Nq, H * 64), device=q.device, dtype=torch.float32)
+    split_out = isinstance(out, SplitAct)
+    if split_out:
+        _split_out_ok(out, B * Nq)
+    assert vt_bs % 2 == 0
+    p = Attention()
+    p.q, p.o, p.ldq, p.ldo = q.data_ptr(), out.data_ptr(), _ld(q) // 2, (_ld(out) // 2 if split_out else _ld(out))
+    p.split_out, p.qkv_split = int(split_out), 1
+    p.k[0], p.vt[0], p.ldk[0], p.ldvt[0], p.vt_bs[0], p.Nk[0], p.kv_div[0] = k.data_ptr(), vt.data_ptr(), _ld(k) // 2, _ld(vt) // 2, vt_bs // 2, nk, div
+    p.zeros = workspace(q.device)[1].data_ptr()
+    p.B, p.H, p.Nq, p.nseg, p.head_dim, p.dtype, p.scale = B, H, Nq, 1, 64, BF16X3, scale
+    p.variant = ATTN_VARIANT if variant is None else variant
+    _launch_attention(lib, p)
+    return out
+
+
+def _launch_attention(lib, p):
+    if ATTN_TIMELINE is not None and p.nseg == 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
+        e1.record()
+        ATTN_TIMELINE.append((4.0 * p.B * p.H * p.Nq * p.Nk[0] * 64, e0, e1))
+        return
+    _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
+
+
+def linear_t_batched(w, x, batch, rows, dtype_align=None, split_out=False):
     """Per-batch operand-swapped projection: x [batch*rows, K] -> out [batch, N, rows_pad] with out[b, n, m] =
-    sum_k w[n, k] x[b*rows + m, k]; rows_pad = rows rounded up to a 16-byte multiple (zero filled). This is V^T per frame."""
+    sum_k w[n, k] x[b*rows + m, k]; rows_pad = rows rounded up to a 16-byte multiple (zero filled). This is V^T per frame.
+    `split_out` (bf16x3, pre-split x): out is a SplitAct [batch, N, 2*rows_pad] (rows_pad a multiple of 8) - V^T in the format the
+    attention kernel takes with qkv_split."""
     N, K = w.shape[0], kdim(w, x)
+    if split_out:
+        assert isinstance(x, SplitAct)
+        rp = (rows + 7) // 8 * 8
+        out = SplitAct.wrap((torch.zeros if rp != rows else torch.empty)((batch, N, 2 * rp), device=x.device, dtype=torch.bfloat16))
+        conv_gemm(w, x, out, M=N, N=rows, K=K, Cin=K, lda=_ld(w), ldw=_ld(x), ldo=2 * rp, batch=batch, a_bs=0, w_bs=rows * _ld(x), o_bs=N * 2 * rp)
+        return out, rp
     odt = _out_dtype(x, None)
     epc = 4 if odt == torch.float32 else 8
     rp = (rows + epc - 1) // epc * epc
@@ -458,6 +530,9 @@ def temporal_attention(q, k, v, *, B, T, HW, H, scale, out=None, split_out=False
     if out is None:
         out = new_split(B * T * HW, H * 64, q.device) if split_out else torch.empty((B * T * HW, H * 64), device=q.device, dtype=q.dtype)
     split_out = isinstance(out, SplitAct)
+    _dev(k, "k"); _dev(v, "v")
+    if split_out:
+        _split_out_ok(out, B * T * HW)
     _lib.check(lib.geo4d_temporal_attention2(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(),
                                              _ld(out) // 2 if split_out else _ld(out), B, T, HW, H, 64, scale, dt_code(q.dtype),
                                              int(split_out), _stream()), "geo4d_temporal_attention")
@@ -482,7 +557,7 @@ def tokens_from_ncthw(src0, src1, cpad, dtype):
 
 def concat_channels(a, b):
     lib = _lib.load()
-    _dev(a, "a")
+    _dev(a, "a"); _dev(b, "b")
     M, Ca = a.shape
     Cb = b.shape[1]
     assert b.shape[0] == M and a.dtype == b.dtype

@@ -427,10 +427,18 @@ class UNetModel(ParamTree):
         sp = self.presplit
         x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=N, eps=1e-6, split_out=sp), *e["in"])
         n1 = ops.layernorm(x, *blk["norm1"], split_out=sp)
-        qk = ops.linear(n1, blk["attn1.qk"])
-        vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
         x3 = self.compute_dtype.x3
-        att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
+        if sp and N % 8 == 0:
+            # bf16x3: q | k and V^T leave their projections in the pre-split operand format (o_split epilogue), so the attention kernel
+            # does not split K / V^T fragments per tile and wave (round 4: -30 % of its VALU instructions). 2 bf16 per element:
+            qk = ops.linear(n1, blk["attn1.qk"], split_out=True)                          # SplitAct [M, 2 * 2C]
+            vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N, split_out=True)    # SplitAct [F, C, 2 * Npad]
+            att = ops.attention(qk[:, :2 * C_], [(qk[:, 2 * C_:], vt.reshape(-1, 2 * npad), N, 1, C_ * 2 * npad)], B=F_, H=heads, Nq=N,
+                                scale=0.125, x3=True, split_out=sp, qkv_split=True)
+        else:
+            qk = ops.linear(n1, blk["attn1.qk"])
+            vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
+            att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn1.o"], residual=x)
         q = ops.linear(ops.layernorm(x, *blk["norm2"], split_out=sp), blk["attn2.q"])
         k_t, k_i, vt_t, vt_i, _ = kv

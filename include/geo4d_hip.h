@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEO4D_ABI_VERSION 4
+#define GEO4D_ABI_VERSION 5
 
 /* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
  * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
@@ -57,30 +57,28 @@ typedef struct geo4d_conv_gemm_t {
     int out_nchw;        /* 1: store O as [B][ldo][T][Hout*Wout] (ldo = channel count of the
                             destination tensor; O may point at a channel offset inside it) */
     int tile_hint;       /* 0 auto; 1..5 = 128x128, 128x64, 64x128, 64x64, 128x32 (4 waves, 2-stage ring);
-                            8 waves, one tile per CU: 11 = 256x128, 13 = 256x256; deep-ring A/B variants:
-                            12 = 256x128 x 3 stages, 14 = 128x128 x 4 stages; 16 = 160x320 with 10 waves
+                            8 waves, one tile per CU: 11 = 256x128, 13 = 256x256; 16 = 160x320 with 10 waves
                             (N = 320 layers: one tile per CU at M = 40960), 17 = 160x160 with 5 waves; no
-                            GEGLU on 16 / 17. Round 3, bf16 / f16 / bf16x3 only (16x16x32 MFMA, register epilogue, persistent
-                            workgroups; no NCTHW output, no gn_colsum): 21 = 256x128, 22 = 256x256, 23 = 160x320 (8 waves,
-                            80x80 wave tiles), 24 = 160x160 (4 waves), 25 = 128x128, 26 = 128x64, 27 = 64x128, 28 = 64x64,
-                            29 = 128x256; the same with THREE activation-panel
-                            buffers (the A panel two K slabs ahead): 31 = 256x128, 33 = 160x320, 34 = 160x160, 35 = 128x128,
-                            39 = 128x256; GEGLU on 21, 22, 25, 27, 29, 31, 35, 39. The same MFMA form and epilogue under a PHASED
-                            K loop (4 phases per slab, counted LDS-DMA waits, two staggered wave groups, the staging cursor
-                            two slabs ahead across tiles; 8 waves, one workgroup per CU): 71 = 192x256, 72 = 160x320,
-                            73 = 256x128, 74 = 128x256; GEGLU on 71, 74; launches with an odd number or fewer than 4 K slabs per tile, an uneven
-                            split-K or outputs that are not 4-element aligned run on 22 / 23 / 21 / 29 instead.
-                            Others: -EINVAL */
+                            GEGLU on 16 / 17. Second generation, bf16 / bf16x3 only (16x16x32 MFMA, register epilogue, persistent
+                            workgroups; no NCTHW output, no gn_colsum): 22 = 256x256, 23 = 160x320 (8 waves, 80x80 wave
+                            tiles), 25 = 128x128, 27 = 64x128, 28 = 64x64 (4 waves); GEGLU on 22, 25, 27. Third generation: the
+                            same MFMA form and epilogue under a PHASED K loop (4 phases per slab, counted LDS-DMA waits, the
+                            staging cursor two slabs ahead across tiles; 8 waves, one workgroup per CU): 71 = 192x256,
+                            72 = 160x320, 73 = 256x128, 74 = 128x256; GEGLU on 71, 74; launches with an odd number or fewer
+                            than 4 K slabs per tile, an uneven split-K or outputs that are not 4-element aligned run on
+                            22 / 23 / 25 / 25 instead (same bits: every tile sums in the same order).
+                            Others (incl. the hints retired in round 4: 12, 14, 21, 24, 26, 29, 31..39): -EINVAL */
     int split_k;         /* 0 auto (powers of two), 1 never, n >= 2: n-way split (needs workspace; tile hints >= 21 take any n) */
-    int debug_ablate;    /* 0 in production. 1 (bf16x3 profiling only): skip the in-register hi/lo split -> WRONG results;
-                            2 (tests only, tile hints >= 21): launch 3 persistent workgroups whatever the problem size */
+    int debug_ablate;    /* 0 in production. 2 (tests only, tile hints >= 22): launch 3 persistent workgroups whatever the problem size,
+                            so that small test shapes walk the persistent tile loop */
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */
-    int o_split;         /* dtype 3 (bf16x3), a_split and w_split set, act 2 (GEGLU), out_dtype F32: O is written in the pre-split operand
+    int o_split;         /* dtype 3 (bf16x3), a_split and w_split set, out_dtype F32: O is written in the pre-split operand
                             format ([8 x bf16 hi | 8 x bf16 lo] per 8 output columns; ldo / o_bs still count columns) - the producer
-                            side of a_split for the GEGLU -> FF-out chain. Stored columns % 8 == 0, aligned rows, no split-K;
-                            served by the GEGLU-capable second-generation tiles (first-generation hints are re-routed) */
+                            side of a_split (GEGLU -> FF-out chain; q | k and V^T of the spatial attention, geo4d_attention_t.qkv_split).
+                            Stored columns % 8 == 0, ldo % 8 == 0, 32-byte aligned rows, no split-K, any epilogue incl. residual;
+                            served by the second- / third-generation tiles (first-generation hints are re-routed) */
     float* gn_colsum;    /* optional [M/32][N][2] fp32: per 32-row block and output column, (sum, sum of squares) of the values this
                             launch stores - the statistics pass of the GroupNorm that consumes O, produced for free by the epilogue
                             (geo4d_groupnorm_t.colsum). Needs M % 32 == 0, N % 8 == 0, row-major 16-byte aligned output, batch 1,
@@ -102,12 +100,6 @@ typedef struct geo4d_groupnorm_t {
     float eps;
     const float* colsum; /* optional: [F*HW/32][C][2] column sums written by the producing geo4d_conv_gemm (gn_colsum); when given
                             (needs HW % 32 == 0) the pass over x that computes the statistics is skipped */
-    void* barrier;       /* optional: 8 bytes of persistent, zero-initialised device memory (one GroupNorm at a time per buffer, i.e.
-                            stream-ordered use). When given and every workgroup can be resident, statistics + merge + apply run as ONE
-                            launch around a grid-wide barrier (bit-identical to the three-launch path); NULL = three launches */
-    void* counters;      /* optional: 4 KiB of persistent, zero-initialised device memory (1024 ticket counters, one per statistic; stream-
-                            ordered use). When given, the statistics launch also merges them (the last workgroup to arrive at a
-                            statistic's counter does it and clears the counter): two launches instead of three, bit-identical */
     int split_out;       /* bf16x3 producers (dtype F32 only, C % 8 == 0): y is written in the PRE-SPLIT operand format of
                             geo4d_conv_gemm_t.a_split - per 8 channels [8 x bf16 hi | 8 x bf16 lo]; ldy still counts channels */
 } geo4d_groupnorm_t;
@@ -144,10 +136,14 @@ typedef struct geo4d_attention_t {
     int Nk[2], kv_div[2];
     int B, H, Nq, nseg, head_dim, dtype;
     float scale;
-    int split_out;       /* dtype 3 (bf16x3) only: o is written in the pre-split operand format of geo4d_conv_gemm_t.a_split (ldo still
+    int split_out;       /* 4-byte storage only (dtype F32 or BF16X3 - the bf16x3 mode stores its activations as f32): o is written in the pre-split operand format of geo4d_conv_gemm_t.a_split (ldo still
                             counts channels) - the to_out projection consumes it without splitting again */
     int variant;         /* 0 = default; A/B builds of the same math: 1 = 128 query rows per workgroup, 2 = the same compiled for
                             4 waves per SIMD (16-bit types), 3 = 256 rows per workgroup, two query blocks per wave (nseg == 1) */
+    int qkv_split;       /* dtype 3 (bf16x3), nseg == 1 only: q, k[0] and vt[0] are stored in the PRE-SPLIT operand format (written by
+                            geo4d_conv_gemm_t.o_split projections): per 8 elements of a row [8 x bf16 hi | 8 x bf16 lo]; ld* / vt_bs still
+                            count 4-byte elements and must be multiples of 8, bases 32-byte aligned, Nk % 8 == 0. Same results, bit
+                            for bit, as the raw-f32 inputs (the split is the same arithmetic, done once by the producer). */
 } geo4d_attention_t;
 int geo4d_attention(const geo4d_attention_t* p, void* stream);
 
@@ -155,7 +151,8 @@ int geo4d_attention(const geo4d_attention_t* p, void* stream);
  * replaces the einsum/softmax path of CrossAttention inside TemporalTransformer (attention.py:101-125, 365-412). */
 int geo4d_temporal_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                              int B, int T, int HW, int H, int head_dim, float scale, int dtype, void* stream);
-/* the same with `split_out` (dtype 3 = bf16x3 only): o in the pre-split operand format, see geo4d_attention_t.split_out */
+/* the same with `split_out` (dtype GEO4D_F32 only = the storage type of the bf16x3 mode; dtype 3 is NOT accepted here): o in the
+ * pre-split operand format, see geo4d_attention_t.split_out */
 int geo4d_temporal_attention2(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                               int B, int T, int HW, int H, int head_dim, float scale, int dtype, int split_out, void* stream);
 

@@ -246,3 +246,21 @@ def test_alignment_sharded_over_two_ranks_equals_single_rank():
         assert torch.equal(tab, torch.arange(len(groups) * 3, dtype=torch.float32).reshape(-1, 3) + 1)
     for k in ref_P:                          # the replicated parameters are bit-identical across ranks (no broadcast needed)
         assert torch.equal(res[0][5][k], res[1][5][k]), k
+
+
+def test_alignment_shard_falls_back_when_windows_fewer_than_ranks():
+    """5 windows on 8 GPUs would hand ranks 5-7 an empty block (the residual kernel refuses an empty slot list while
+    ranks 0-4 wait in the per-iteration all-reduce -> hang). make_shard() - what post_optimization builds its shard with - returns None
+    (= replicated optimisation, no collective) on EVERY rank in that case, and a shard with a non-empty block on every rank otherwise."""
+    from geo4d_amd.align_dist import AlignShard, make_shard
+    groups5 = [list(range(4 * w, 4 * w + 16)) for w in range(5)]
+    assert all(make_shard(groups5, 32, rank=r, world=8) is None for r in range(8))
+    assert [len(AlignShard(groups5, 32, rank=r, world=8).local_groups) for r in range(8)] == [1, 1, 1, 1, 1, 0, 0, 0]   # why
+    groups8 = [list(range(4 * w, 4 * w + 16)) for w in range(8)]
+    shards = [make_shard(groups8, 44, rank=r, world=8) for r in range(8)]
+    assert all(s is not None and len(s.local_groups) == 1 for s in shards)
+    assert make_shard(groups8, 44, rank=0, world=1) is None                     # a single rank never shards
+    # the aligner itself refuses an empty block loudly instead of handing the kernel a null slot list (no GPU needed to see the message)
+    import inspect
+    from geo4d_amd import align
+    assert "owns no window" in inspect.getsource(align.GroupAligner.__init__)

@@ -1,0 +1,70 @@
+"""The `dust3r/inference.py` call surface (reference: /root/reference/dust3r/inference.py:27-179,
+dust3r/utils/device.py:10-75) on the host, with a stub pairwise model: batching, collation, the batch-size-1 fallback for images of
+different sizes, symmetrised batches. No GPU, no reference import (the behaviours are stated here as plain expectations)."""
+import numpy as np
+import torch
+
+from geo4d_amd import dust3r_inference as di
+
+
+def _view(i, h=4, w=6):
+    g = torch.Generator().manual_seed(i)
+    return {"img": torch.randn((1, 3, h, w), generator=g), "true_shape": np.int32([[h, w]]), "idx": i, "instance": str(i)}
+
+
+class StubModel:
+    """pred1['pts3d'] = mean colour of view1 per pixel; pred2['pts3d_in_other_view'] = view2 - view1 means: enough to see which inputs
+    reached the model, in which order, and how many calls were made."""
+    def __init__(self):
+        self.batch_sizes = []
+
+    def __call__(self, v1, v2):
+        self.batch_sizes.append(v1["img"].shape[0])
+        a, b = v1["img"].mean(1, keepdim=True).permute(0, 2, 3, 1), v2["img"].mean(1, keepdim=True).permute(0, 2, 3, 1)
+        return {"pts3d": a.expand(-1, -1, -1, 3), "conf": torch.ones_like(a[..., 0])}, {"pts3d_in_other_view": (b - a).expand(-1, -1, -1, 3)}
+
+
+def test_inference_batches_and_collates():
+    pairs = [(_view(2 * k), _view(2 * k + 1)) for k in range(5)]
+    m = StubModel()
+    out = di.inference(pairs, m, "cpu", batch_size=2, verbose=False)
+    assert m.batch_sizes == [2, 2, 1]
+    assert set(out) == {"view1", "view2", "pred1", "pred2", "loss"} and out["loss"] is None
+    assert out["view1"]["img"].shape == (5, 3, 4, 6) and out["pred1"]["pts3d"].shape == (5, 4, 6, 3)
+    for k in range(5):
+        assert torch.equal(out["view1"]["img"][k], pairs[k][0]["img"][0]) and torch.equal(out["view2"]["img"][k], pairs[k][1]["img"][0])
+        want = pairs[k][1]["img"][0].mean(0) - pairs[k][0]["img"][0].mean(0)
+        assert torch.allclose(out["pred2"]["pts3d_in_other_view"][k, ..., 0], want, atol=1e-6)
+    assert out["view1"]["idx"] == [0, 2, 4, 6, 8] and out["view2"]["instance"] == ["1", "3", "5", "7", "9"]       # scalars chain as lists
+    assert torch.is_tensor(out["view1"]["true_shape"]) and out["view1"]["true_shape"].shape == (5, 2)           # numpy -> concatenated tensor
+    assert di.get_pred_pts3d(out["view1"], out["pred1"]) is out["pred1"]["pts3d"]
+    assert di.get_pred_pts3d(out["view2"], out["pred2"], use_pose=True) is out["pred2"]["pts3d_in_other_view"]
+
+
+def test_inference_mixed_sizes_forces_batch_one_and_lists():
+    pairs = [(_view(0), _view(1)), (_view(2, 5, 7), _view(3, 5, 7))]
+    assert not di.check_if_same_size(pairs) and di.check_if_same_size(pairs[:1])
+    m = StubModel()
+    out = di.inference(pairs, m, "cpu", batch_size=8, verbose=False)
+    assert m.batch_sizes == [1, 1]
+    assert isinstance(out["view1"]["img"], list) and [tuple(t.shape) for t in out["view1"]["img"]] == [(3, 4, 6), (3, 5, 7)]
+    assert [tuple(t.shape) for t in out["pred1"]["pts3d"]] == [(4, 6, 3), (5, 7, 3)]
+
+
+def test_collate_and_to_cpu_edge_cases():
+    assert di.collate_with_cat([]) == [] and di.collate_with_cat([None, None]) is None
+    assert di.collate_with_cat([1, 2]) == [1, 2] and di.collate_with_cat([[1], [2, 3]]) == [1, 2, 3]
+    t = di.collate_with_cat([(torch.zeros(1, 2), {"a": torch.ones(1)}), (torch.ones(2, 2), {"a": torch.zeros(3)})])
+    assert isinstance(t, list) and t[0].shape == (3, 2) and t[1]["a"].shape == (4,)
+    moved = di.to_cpu({"a": (torch.ones(2), np.zeros(3)), "b": [None, "s", 3]})
+    assert isinstance(moved["a"], tuple) and torch.is_tensor(moved["a"][1]) and moved["b"] == [None, "s", 3]
+
+
+def test_symmetrized_batch_and_loss_hook():
+    v1, v2 = di.collate_with_cat([(_view(0), _view(1)), (_view(2), _view(3))])
+    s1, s2 = di.make_batch_symmetric((v1, v2))
+    assert s1["img"].shape[0] == 4 and torch.equal(s1["img"][0], v1["img"][0]) and torch.equal(s1["img"][1], v2["img"][0])
+    assert torch.equal(s2["img"][0], v2["img"][0]) and s1["idx"] == [0, 1, 2, 3] and s2["idx"] == [1, 0, 3, 2]
+    res = di.loss_of_one_batch((v1, v2), StubModel(), lambda a, b, p1, p2: p1["pts3d"].sum() * 0 + 7.0, "cpu", symmetrize_batch=True)
+    assert float(res["loss"]) == 7.0 and res["pred1"]["pts3d"].shape[0] == 4
+    assert di.loss_of_one_batch((v1, v2), StubModel(), None, "cpu", ret="pred2")["pts3d_in_other_view"].shape[0] == 2

@@ -1,5 +1,6 @@
-"""Second-generation conv_gemm kernel (tile hints 21..39: 16x16x32 MFMA, register epilogue, persistent workgroups;
-geo4d_amd/csrc/gemm_kernel_v2.h) against plain PyTorch fp32 math, every element type it serves (bf16, f16, bf16x3), through the C ABI.
+"""Second-generation conv_gemm kernel (tile hints 22 / 23 / 25 / 27 / 28 after the round-4 pruning: 16x16x32 MFMA, register epilogue,
+persistent workgroups; geo4d_amd/csrc/gemm_kernel_v2.h) against plain PyTorch fp32 math, every element type it serves (bf16, bf16x3;
+f16 stays on the first generation), through the C ABI.
 Each case runs twice: with the production grid and with `debug_ablate = 2` (3 workgroups: the persistent tile loop, the next-tile
 prefetch under the epilogue and the gather-table reuse are exercised on small shapes), and the two must agree bit for bit."""
 import math
@@ -10,9 +11,9 @@ import torch.nn.functional as TF
 
 pytestmark = pytest.mark.gpu
 
-V2_TILES = [21, 22, 23, 24, 25, 26, 27, 28, 29, 31, 33, 34, 35, 39]      # 31..39: three A-panel buffers (counted vmcnt, raw barrier)
-GEGLU_TILES = {21, 22, 25, 27, 29, 31, 35, 39}
-MODES = ["bf16", "f16", "bf16x3"]
+V2_TILES = [22, 23, 25, 27, 28]
+GEGLU_TILES = {22, 25, 27}
+MODES = ["bf16", "bf16x3"]
 TOL = {"bf16": 6e-3, "f16": 1e-3, "bf16x3": 3e-5}
 
 
@@ -115,7 +116,7 @@ def test_conv3x3_rowbias_residual_split_k(dev, mode, tile, cfg):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("tile", [21, 23, 24, 28, 31, 33, 34])
+@pytest.mark.parametrize("tile", [22, 23, 25, 28])
 def test_temporal_conv(dev, mode, tile):
     from geo4d_amd import ops, pack
     B, T, HW, C = 2, 7, 45, 128
@@ -129,7 +130,7 @@ def test_temporal_conv(dev, mode, tile):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("tile", [21, 25, 28])
+@pytest.mark.parametrize("tile", [22, 25, 28])
 def test_unaligned_output_takes_the_scalar_path(dev, mode, tile):
     """N = 77 columns with a row pitch of 77 elements: 4-element vectors are not aligned, the epilogue must fall back to scalar stores."""
     from geo4d_amd import ops, pack
@@ -147,10 +148,10 @@ def test_ncthw_and_f32_are_refused(dev, mode):
     x = rnd((F * H * W, Ci), dev, 40).to(act_dtype(mode))
     w3, b3 = rnd((3, Ci, 3, 3), dev, 41, 0.03), rnd((3,), dev, 42)
     with pytest.raises(RuntimeError):
-        ops.conv2d(x, pack.pack_conv2d(w3, pack_mode(mode)), b3, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, T=1, out_nchw=True, tile_hint=21)
+        ops.conv2d(x, pack.pack_conv2d(w3, pack_mode(mode)), b3, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, T=1, out_nchw=True, tile_hint=22)
     xf, wf = rnd((64, 64), dev, 43), rnd((64, 64), dev, 44)
     with pytest.raises(RuntimeError):
-        ops.linear(xf, wf, None, tile_hint=21)          # exact-f32 mode
+        ops.linear(xf, wf, None, tile_hint=22)          # exact-f32 mode
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -162,7 +163,7 @@ def test_full_chip_persistent_rounds_are_deterministic(dev, mode):
     x, w, b = rnd((M, K), dev, 50).to(act_dtype(mode)), rnd((N, K), dev, 51, 0.03), rnd((N,), dev, 52)
     r = rnd((M, N), dev, 53).to(act_dtype(mode))
     wp = pack.pack_linear(w, pack_mode(mode))
-    for tile in (28, 25, 21, 23, 35, 31, 33):
+    for tile in (28, 25, 22, 23, 27):
         outs = [ops.linear(x, wp, b, residual=r, tile_hint=tile) for _ in range(3)]
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"tile {tile}: runs differ"

@@ -311,3 +311,21 @@ def test_third_generation_tile_hints_validate_on_the_host():
     for tile in (70, 75, 79):
         assert lib.geo4d_conv_gemm(ctypes.byref(desc(BF16, tile)), None) == -22
         assert b"tile_hint" in lib.geo4d_last_error(), lib.geo4d_last_error()
+
+
+def test_split_act_is_rejected_outside_gemm_operands():
+    """a SplitAct (bf16 [rows, 2K] hi | lo image) reaching a kernel that expects plain activations would be silently
+    reinterpreted; `ops._dev` refuses it everywhere except conv_gemm's operands, and producers only write whole contiguous matrices."""
+    import pytest
+    import torch
+    from geo4d_amd import ops
+
+    class FakeCuda(ops.SplitAct):          # a SplitAct that claims to live on a HIP device (no GPU in this test)
+        is_cuda = True
+    t = torch.zeros((4, 32), dtype=torch.bfloat16).as_subclass(FakeCuda)
+    with pytest.raises(TypeError, match="only GEMM operands"):
+        ops._dev(t, "q")
+    assert ops._dev(t, "A", True) is t
+    with pytest.raises(AssertionError, match="no column-offset views"):
+        ops._split_out_ok(torch.zeros((4, 64), dtype=torch.bfloat16)[:, 16:48].as_subclass(ops.SplitAct), 4)
+    ops._split_out_ok(ops.SplitAct.wrap(torch.zeros((4, 32), dtype=torch.bfloat16)), 4)

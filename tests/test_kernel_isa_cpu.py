@@ -102,8 +102,9 @@ def test_built_library_has_no_scratch_outside_the_ab_variants():
         pytest.skip("library or llvm-readelf missing")
     ks = skt.kernels(lib)
     names = skt.demangle([k["name"] for k in ks])
-    assert len(ks) > 200 and sum(1 for n in names if n.startswith("conv_gemm_v3_kernel")) >= 20, len(ks)
-    allowed = {"flash_attn_kernel<float, 1, 2, 2>", "flash_attn_kernel<bf16x3_t, 1, 2, 2>", "flash_attn_kernel<bf16_t, 1, 1, 4>", "flash_attn_kernel<f16_t, 1, 1, 4>"}
+    assert len(ks) > 150 and sum(1 for n in names if n.startswith("conv_gemm_v3_kernel")) >= 16, len(ks)     # (round 4 pruned ~100 instantiations)
+    allowed = {"flash_attn_kernel<float, 1, 2, 2, false>", "flash_attn_kernel<bf16x3_t, 1, 2, 2, false>", "flash_attn_kernel<bf16x3_t, 1, 2, 2, true>",
+               "flash_attn_kernel<bf16_t, 1, 1, 4, false>", "flash_attn_kernel<f16_t, 1, 1, 4, false>"}
     bad = [(n, k["scratch"]) for k, n in zip(ks, names) if k["scratch"] and n not in allowed]
     assert not bad, bad
     assert all(k["vgpr"] <= 256 for k, n in zip(ks, names) if n.startswith("conv_gemm"))       # 8-wave tiles: two waves per SIMD

@@ -34,7 +34,7 @@ def rnd(shape, dev, dtype, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 16, 17])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 11, 13, 16, 17])
 def test_linear_bias_residual(dev, dtype, tile):
     from geo4d_amd import ops
     M, K, N = 300, 320, 200  # ragged M and N
@@ -86,9 +86,9 @@ def test_geglu(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [11, 12, 13, 14, 16, 17])
+@pytest.mark.parametrize("tile", [11, 13, 16, 17])
 def test_big_tiles_geglu_and_deep_conv(dev, dtype, tile):
-    """The 8-wave / deep-ring configurations (tile hints 11-15): GEGLU epilogue with 128-wide wave tiles, and a 3x3 conv
+    """The 8- / 10- / 5-wave configurations (tile hints 11, 13, 16, 17): GEGLU epilogue with 128-wide wave tiles, and a 3x3 conv
     whose K loop (36 slabs in 16-bit) is longer than any ring, ragged M and N, with split-K 2 as well."""
     from geo4d_amd import ops, pack
     M, K, inner = 700, 256, 320
@@ -417,7 +417,7 @@ def test_lds_dma_pipelines_are_race_free(dev, dtype):
     check("attn full-chip", first, ref, dtype, scale=2.0)
     M, K, Nn = 10240, 5760, 640
     x, w = rnd((M, 640), dev, dtype, 72), rnd((Nn, K), dev, dtype, 73, 0.02)
-    outs = [ops.conv2d(x, w, None, F=16, Hin=20, Win=32, KH=3, KW=3, pad=1, tile_hint=t, split_k=1)[0] for t in (1, 1, 1, 2, 3, 4, 11, 12, 12, 13, 13, 14, 14, 16, 16, 17, 17)]   # same split => same fp32 association
+    outs = [ops.conv2d(x, w, None, F=16, Hin=20, Win=32, KH=3, KW=3, pad=1, tile_hint=t, split_k=1)[0] for t in (1, 1, 1, 2, 3, 4, 11, 11, 13, 13, 16, 16, 17, 17)]   # same split => same fp32 association
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "conv_gemm output depends on launch / tile shape"
 

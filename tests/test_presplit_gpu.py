@@ -1,4 +1,4 @@
-"""bf16x3 producer / consumer chain in the PRE-SPLIT operand format (round 3) and the one-launch GroupNorm.
+"""bf16x3 producer / consumer chain in the PRE-SPLIT operand format (rounds 3-4).
 
 Producers (GroupNorm, LayerNorm, both attention kernels, the GEGLU epilogue) can write their f32 result as [8 x bf16 hi | 8 x bf16 lo]
 per 8 channels (ops.SplitAct); conv_gemm then multiplies it without splitting fragments in its K loop. Checked here:
@@ -6,7 +6,8 @@ per 8 channels (ops.SplitAct); conv_gemm then multiplies it without splitting fr
   * conv_gemm on a SplitAct A operand (linear / 3x3 conv with gather + zero padding / temporal conv / operand-swapped V^T projection)
     equals conv_gemm on the same values given as raw f32 BIT FOR BIT (the split happens before the MFMA either way), on first- and
     second-generation tiles;
-  * GroupNorm in one launch (grid barrier) == GroupNorm in three launches bit for bit, 4-D and 5-D statistics, and when repeated."""
+  * (round 4) every GEMM epilogue can write the pre-split format (q | k and V^T projections), and the spatial attention kernel fed with
+    pre-split q / K / V^T equals the kernel fed with raw f32 bit for bit."""
 import pytest
 import torch
 import torch.nn.functional as TF
@@ -41,50 +42,31 @@ def make_split(x):
 
 
 @pytest.mark.parametrize("case", [(4, 6 * 7, 320, 1, True), (6, 5 * 4, 64, 3, False), (2, 70 * 33, 128, 1, True), (16, 160, 1280, 16, True)])
-def test_groupnorm_split_output_and_one_launch(dev, case):
+def test_groupnorm_split_output(dev, case):
     from geo4d_amd import ops
     F, HW, C, fps, silu = case
     x = rnd((F * HW, C), dev, 1) * 2 + 0.5
     g, b = rnd((C,), dev, 2) + 1, rnd((C,), dev, 3)
-    one, two = ops.GN_ONE_LAUNCH, ops.GN_TWO_LAUNCH
-    ops.GN_ONE_LAUNCH = ops.GN_TWO_LAUNCH = False
-    try:
-        y3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
-        s3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
-        ops.GN_TWO_LAUNCH = True
-        y2 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
-        y2b = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)      # the ticket counters reset themselves
-        ops.GN_ONE_LAUNCH = True
-        y1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
-        y1b = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)      # the barrier resets itself
-        s1 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
-    finally:
-        ops.GN_ONE_LAUNCH, ops.GN_TWO_LAUNCH = one, two
-    assert torch.equal(y2, y3) and torch.equal(y2, y2b), "two-launch GroupNorm (last arriver merges) differs from the three-launch path"
-    assert torch.equal(y1, y3) and torch.equal(y1, y1b), "one-launch GroupNorm differs from the three-launch path"
-    assert torch.equal(s1.as_subclass(torch.Tensor), s3.as_subclass(torch.Tensor))
+    y3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
+    y3b = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu)
+    s3 = ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=silu, split_out=True)
+    assert torch.equal(y3, y3b), "GroupNorm is order-deterministic"
     ref = TF.group_norm(x.reshape(F // fps, fps * HW, C).permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1).reshape(F * HW, C)
     if silu:
         ref = TF.silu(ref)
-    assert ((y1 - ref).norm() / ref.norm()).item() < 2e-5
-    check_split(f"groupnorm {case}", s1, y1)
+    assert ((y3 - ref).norm() / ref.norm()).item() < 2e-5
+    check_split(f"groupnorm {case}", s3, y3)
 
 
-def test_groupnorm_one_launch_many_in_a_row_and_big_grid(dev):
-    """Back-to-back one-launch GroupNorms on one stream share the barrier words; a tensor whose default chunking exceeds the resident
-    workgroup count takes longer chunks (VAE-sized: 48 frames x 40x64 x 512 channels)."""
+def test_groupnorm_vae_sized_back_to_back(dev):
+    """VAE-sized tensor (48 frames x 40x64 x 512 channels), several GroupNorms in a row on one stream: bit-identical every time."""
     from geo4d_amd import ops
     F, HW, C = 48, 2560, 512
     x = rnd((F * HW, C), dev, 5)
     g, b = rnd((C,), dev, 6) + 1, rnd((C,), dev, 7)
-    outs = [ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-6, silu=True) for _ in range(6)]
-    ops.GN_ONE_LAUNCH = True
-    try:
-        outs += [ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-6, silu=True) for _ in range(3)]
-    finally:
-        ops.GN_ONE_LAUNCH = False
+    outs = [ops.groupnorm(x, g, b, F=F, HW=HW, eps=1e-6, silu=True) for _ in range(4)]
     torch.cuda.synchronize()
-    assert all(((outs[0] - o).abs().max() < 1e-5) for o in outs[1:]) and all(torch.equal(outs[0], o) for o in outs[1:6])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     ref = TF.silu(TF.group_norm(x.reshape(F, HW, C).permute(0, 2, 1), 32, g, b, 1e-6).permute(0, 2, 1).reshape(F * HW, C))
     assert ((outs[0] - ref).norm() / ref.norm()).item() < 2e-5
 
@@ -115,7 +97,7 @@ def test_attention_kernels_split_output(dev):
     check_split("temporal", ops.temporal_attention(q3[:, :C_], q3[:, C_:2 * C_], q3[:, 2 * C_:], B=Bt, T=T, HW=HW, H=H, scale=0.125, split_out=True), plain)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3, 11, 13, 16, 17, 21, 22, 23, 25, 28, 31, 33])
+@pytest.mark.parametrize("tile", [0, 1, 3, 11, 13, 16, 17, 22, 23, 25, 27, 28, 71, 72, 73, 74])
 def test_gemm_on_presplit_activations_equals_raw(dev, tile):
     from geo4d_amd import ops, pack
     M, K, N = 1000, 320, 456
@@ -155,7 +137,7 @@ def test_operand_swapped_projection_and_geglu_split_output(dev):
     xg = rnd((M, K), dev, 42)
     w, bb = rnd((2 * inner, K), dev, 43, 0.1), rnd((2 * inner,), dev, 44)
     wp, bp = pack.pack_geglu(w, bb, "bf16x3")
-    for tile in (0, 1, 11, 13, 21, 22, 25, 27, 29, 31):
+    for tile in (0, 1, 11, 13, 22, 25, 27, 71, 74):
         plain = ops.linear(xg, wp, bp, act=2, tile_hint=tile)
         split = ops.linear(make_split(xg), wp, bp, act=2, tile_hint=tile, split_out=True)
         hi, lo = decode_split(split)
@@ -192,3 +174,56 @@ def test_presplit_network_equals_raw_network(dev):
     ref = ((outs[True].cpu() - c["out"]).norm() / c["out"].norm()).item()
     print(f"[presplit vs raw tiny U-Net] rel_l2 = {e:.3e}; vs reference {ref:.3e}")
     assert e < 5e-5 and ref < 2e-4     # two bf16x3 evaluations with different tiles: each is ~2.5e-5 from the reference
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 4, 11, 13, 16, 22, 23, 25, 27, 28, 71, 72, 73, 74])
+def test_plain_epilogue_split_output(dev, tile):
+    """Round 4: o_split on the plain epilogue (bias / residual / SiLU), every second- and third-generation tile (first-generation hints
+    are re-routed): the split output is exactly the split of the plain f32 output of the same launch configuration."""
+    from geo4d_amd import ops, pack
+    M, K, N = 1000, 512, 456          # ragged in M and N for every tile; 16 K slabs (even, >= 4: the phased tiles take it)
+    x, w, b = rnd((M, K), dev, 50), rnd((N, K), dev, 51, 0.05), rnd((N,), dev, 52)
+    r = rnd((M, N), dev, 53)
+    wp = pack.pack_linear(w, "bf16x3")
+    xs = make_split(x)
+    for kw in (dict(), dict(residual=r), dict(act=1)):
+        plain = ops.linear(xs, wp, b, tile_hint=tile, **kw)
+        split = ops.linear(xs, wp, b, tile_hint=tile, split_out=True, **kw)
+        assert isinstance(split, ops.SplitAct) and split.shape == (M, 2 * N)
+        hi, lo = decode_split(split)
+        want_hi = plain.to(torch.bfloat16).float()
+        assert torch.equal(hi, want_hi), f"tile {tile} {list(kw)}: hi"
+        assert torch.equal(lo, (plain - want_hi).to(torch.bfloat16).float()), f"tile {tile} {list(kw)}: lo"
+    with pytest.raises(RuntimeError):                      # the reduce kernel writes plain f32: no split-K with o_split
+        ops.linear(xs, wp, b, tile_hint=25, split_k=2, split_out=True)
+
+
+def test_spatial_attention_on_presplit_qkv_equals_raw(dev):
+    """q | k (one GEMM, N = 2C) and V^T (operand-swapped, batched per frame) written pre-split by their projections; the flash kernel on
+    those (qkv_split) == the flash kernel on the raw f32 projections, bit for bit; ragged last key tile (N = 200 = 3 x 64 + 8)."""
+    from geo4d_amd import ops, pack
+    for F, N, H in ((3, 200, 5), (2, 2560, 5), (2, 40, 20)):
+        C = 64 * H
+        n1 = rnd((F * N, C), dev, 60)
+        wqk = pack.pack_linear(rnd((2 * C, C), dev, 61, 0.05), "bf16x3")
+        wv = pack.pack_linear(rnd((C, C), dev, 62, 0.05), "bf16x3")
+        xs = make_split(n1)
+        qk = ops.linear(xs, wqk)
+        vt, npad = ops.linear_t_batched(wv, xs, F, N)
+        raw = ops.attention(qk[:, :C], [(qk[:, C:], vt.reshape(-1, npad), N, 1, C * npad)], B=F, H=H, Nq=N, scale=0.125, x3=True)
+        qks = ops.linear(xs, wqk, split_out=True)
+        vts, npad2 = ops.linear_t_batched(wv, xs, F, N, split_out=True)
+        assert npad2 % 8 == 0 and vts.shape == (F, C, 2 * npad2)
+        h, l = decode_split(vts.reshape(F * C, 2 * npad2))
+        assert torch.equal(h[:, :N], vt.reshape(F * C, npad)[:, :N].to(torch.bfloat16).float())
+        for so in (False, True):
+            pre = ops.attention(qks[:, :2 * C], [(qks[:, 2 * C:], vts.reshape(-1, 2 * npad2), N, 1, C * 2 * npad2)], B=F, H=H, Nq=N,
+                                scale=0.125, x3=True, qkv_split=True, split_out=so)
+            if so:
+                check_split(f"attention qkv_split F{F} N{N}", pre, raw)
+            else:
+                assert torch.equal(pre, raw), f"F{F} N{N}: {((pre - raw).norm() / raw.norm()).item():.3e}"
+        q, k = qk[:, :C].reshape(F, N, H, 64).permute(0, 2, 1, 3), qk[:, C:].reshape(F, N, H, 64).permute(0, 2, 1, 3)
+        v = vt.reshape(F, H, 64, npad)[..., :N].permute(0, 1, 3, 2)
+        ref = TF.scaled_dot_product_attention(q.double(), k.double(), v.double()).permute(0, 2, 1, 3).reshape(F * N, C).float()
+        assert ((raw - ref).norm() / ref.norm()).item() < 3e-5

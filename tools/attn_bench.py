@@ -10,15 +10,22 @@ for name in (sys.argv[1:] or ["bf16"]):
     x3 = name == "bf16x3"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "bf16x3": torch.float32}[name]
     passes = 3 if x3 else 1
-    for variant in (1, 2, 3):
-        if variant == 2 and dt == torch.float32:
+    for variant in (1, 2, 3, "1ps", "3ps"):
+        ps = isinstance(variant, str)                  # bf16x3 only: q | k and V^T in the producers' pre-split format (qkv_split, round 4)
+        if (variant == 2 and dt == torch.float32) or (ps and not x3):
             continue
+        vnum = int(variant[0]) if ps else variant
         tot_ms = 0
         for F_, H, N, cnt in LEVELS:
             C_ = H * 64
             qk = torch.randn((F_ * N, 2 * C_), device=dev).to(dt)
             vt = torch.randn((F_ * C_, N), device=dev).to(dt)
-            fn = lambda: ops.attention(qk[:, :C_], [(qk[:, C_:], vt, N, 1, C_ * N)], B=F_, H=H, Nq=N, scale=0.125, x3=x3, variant=variant)
+            if ps:
+                from geo4d_amd import pack
+                qs, vs = ops.SplitAct.wrap(pack.split_bf16(qk)), ops.SplitAct.wrap(pack.split_bf16(vt))
+                fn = lambda: ops.attention(qs[:, :2 * C_], [(qs[:, 2 * C_:], vs, N, 1, C_ * 2 * N)], B=F_, H=H, Nq=N, scale=0.125, x3=True, variant=vnum, qkv_split=True)
+            else:
+                fn = lambda: ops.attention(qk[:, :C_], [(qk[:, C_:], vt, N, 1, C_ * N)], B=F_, H=H, Nq=N, scale=0.125, x3=x3, variant=variant)
             for _ in range(3): fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

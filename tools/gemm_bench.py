@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--vendor", action="store_true", help="also time the vendor library on the same shape (hipBLASLt via F.linear, MIOpen via F.conv2d channels_last): a calibration point, never used by the product path")
     ap.add_argument("--explore", action="store_true", help="time every (tile, split) pair per shape and report the best")
+    ap.add_argument("--explore-all", action="store_true", help="per shape: every candidate of the host tuner (ops._CANDIDATES, all three kernel generations x split-K) "
+                    "at `--iters` launches each, the 6 best re-measured interleaved; prints the table's choice next to the best (round 4: the tuner's own sample was too noisy)")
     ap.add_argument("--explore2", action="store_true", help="per shape: best 32x32-MFMA configuration (tile hints 1..17) vs best second-generation one (21..29), and every 21..29 tile at split 1")
     ap.add_argument("--tiles", default="", help="comma list of tile hints to time per shape (split 1), e.g. the ablation builds 40..64")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands: same instruction stream, no data toggling (how much of the time is the chip's power-limited clock?)")
@@ -101,7 +103,8 @@ def main():
             b = torch.randn((N,), device=dev)
             act = 2 if kind == "geglu" else 0
             xa = acast(x)
-            fn = lambda tile=args.tile, split=args.split: ops.linear(xa, w, b, act=act, tile_hint=tile, split_k=split)
+            so = bool(x3 and args.presplit and kind == "geglu")      # the network's GEGLU writes the pre-split format for the ff-out GEMM
+            fn = lambda tile=args.tile, split=args.split: ops.linear(xa, w, b, act=act, tile_hint=tile, split_k=split, split_out=so)
         def timeit(**kw):
             for _ in range(2):
                 fn(**kw)
@@ -116,12 +119,17 @@ def main():
         vend = None
         if args.vendor:
             import torch.nn.functional as Fn
-            if kind == "c3":
+            if kind == "c3" and x3:
+                vfn = None
+            elif kind == "c3":
                 xi = x.view(F_, H, W, Cin).permute(0, 3, 1, 2)     # channels_last view
                 wi = w.view(N, 3, 3, Cin).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
                 vfn = lambda: Fn.conv2d(xi, wi, b.to(dt), padding=1)
             elif kind == "t3":
                 vfn = None
+            elif x3:     # bf16x3: the vendor library has no such mode; 3 x its bf16 time is the bound a 3-pass scheme can be held to
+                xb, wb, bb = x.to(torch.bfloat16), torch.randn((N, K), device=dev).to(torch.bfloat16), b.to(torch.bfloat16)
+                vfn = lambda: Fn.linear(xb, wb, bb)
             else:
                 vfn = lambda: Fn.linear(x, w, b.to(dt))
             if vfn is not None:
@@ -145,6 +153,26 @@ def main():
             res.sort()
             print("    auto %.1f us | best: %s" % (us, "  ".join("t%d/s%d %.1f" % (t, s2, u) for u, t, s2 in res[:6])))
             us = min(us, res[0][0])
+        if args.explore_all:
+            res = []
+            for tile, split in ops._CANDIDATES:
+                try:
+                    res.append((timeit(tile=tile, split=split), tile, split))
+                except RuntimeError:
+                    pass
+            res.sort()
+            fin = {(t, s2): u for u, t, s2 in res[:6]}
+            for _ in range(2):
+                for (t, s2) in list(fin):
+                    fin[(t, s2)] = min(fin[(t, s2)], timeit(tile=t, split=s2))
+            order = sorted(fin.items(), key=lambda kv: kv[1])
+            print("    table %.1f us | best: %s" % (us, "  ".join("t%d/s%d %.1f" % (t, s2, u) for (t, s2), u in order)))
+            exp_tot = globals().setdefault("_TOTX", [0.0])
+            exp_tot[0] += min(us, order[0][1]) * cnt / 1e3
+            best_cfg = globals().setdefault("_BESTCFG", {})
+            best_cfg[name] = (order[0][0], order[0][1], us)
+            us_table = us
+            us = min(us, order[0][1])
         if args.tiles:
             row = []
             for t in args.tiles.split(","):
@@ -175,9 +203,14 @@ def main():
         tf = 2.0 * M * N * K / us / 1e6
         tot_ms += us * cnt / 1e3
         tot_tf += 2.0 * M * N * K * cnt / 1e12
-        print(f"{name:34s} {M:8d} {N:6d} {K:6d} {us:9.1f} {tf:8.1f}  x{cnt:3d} -> {us * cnt / 1e3:7.2f}" + (f"   vendor {vend:8.1f} us ({us / vend:4.2f}x ours/vendor)" if vend else ""))
+        print(f"{name:34s} {M:8d} {N:6d} {K:6d} {us:9.1f} {tf:8.1f}  x{cnt:3d} -> {us * cnt / 1e3:7.2f}" + (f"   vendor {vend:8.1f} us ({us / vend:4.2f}x ours/vendor)" if vend and not x3 else "") +
+              (f"   3 x vendor bf16 {3 * vend:8.1f} us ({us / (3 * vend):4.2f}x ours/bound)" if vend and x3 else ""))
     if tot_ms:
         print(f"U-Net GEMM census: {tot_tf:.2f} TFLOP in {tot_ms:.1f} ms = {tot_tf / tot_ms * 1e3:.0f} TF/s")
+    if args.explore_all:
+        print(f"census with the best candidate per shape: {globals()['_TOTX'][0]:.1f} ms")
+        for nm, (cfg, u, ut) in globals()["_BESTCFG"].items():
+            print(f"  {nm:34s} best t{cfg[0]}/s{cfg[1]} {u:8.1f} us   table {ut:8.1f} us   ({ut / u:4.2f}x)")
     if args.explore2:
         t1, t2 = globals()["_TOT2"]
         print(f"census with the best 32x32-MFMA configuration per shape: {t1:.1f} ms; with the best 21..29 configuration per shape: {t2:.1f} ms")

@@ -1,0 +1,54 @@
+#!/bin/bash
+# One entry point for the GPU-box jobs of a round: `gpurun --timeout N -- 'bash tools/gpu_jobs.sh <job> [args]'`.
+# Every job writes under gpurun_out/<tag>/ (merged back by gpurun); summaries worth judging are copied into profiles/ by hand.
+# (Rounds 2-3 kept one script per call under tools/r0*_runs/: those are in the history; this file replaces the pattern.)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+JOB=${1:?job name}; shift
+TAG=${TAG:-r4_$JOB}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+show() { grep -v "amdgpu.ids" "$1" | cut -c1-${2:-260}; }
+
+case $JOB in
+  census)      # per-shape GEMM census: every tuner candidate per shape vs the committed table, vendor calibration next to it
+    MODE=${1:-bf16x3}
+    if [ "$MODE" = bf16x3 ]; then EXTRA="--presplit"; else EXTRA=""; fi
+    timeout 900 python tools/gemm_bench.py --dtype $MODE $EXTRA --iters 10 --explore-all --vendor > $O/census_$MODE.log 2>&1
+    show $O/census_$MODE.log | grep -v "^    table" | tail -70
+    ;;
+  retune)      # re-measure the tuning table with the two-stage tuner (modes as arguments), keep the result for the next steps
+    timeout 1500 python tools/tune_gemm.py $O/gfx950.json "$@" > $O/tune.log 2>&1; show $O/tune.log | tail -5
+    ;;
+  bench)       # bench line (arguments passed through)
+    timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err; cut -c1-1500 $O/bench.json
+    ;;
+  attn)
+    timeout 600 python tools/attn_bench.py "$@" > $O/attn.log 2>&1; show $O/attn.log
+    ;;
+  r4a)         # first call of round 4: where do the linears stand (all generations, vendor), is the table mis-tuned, what does a re-tune buy
+    timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench_old_table.json 2> $O/bench_old.err; cut -c1-400 $O/bench_old_table.json
+    TAG=$TAG bash $0 census bf16x3
+    TAG=$TAG bash $0 census bf16
+    TAG=$TAG bash $0 retune bf16x3 bf16
+    cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_new_table.json 2> $O/bench_new.err; cut -c1-400 $O/bench_new_table.json
+    timeout 300 python tools/attn_bench.py bf16 bf16x3 > $O/attn.log 2>&1; show $O/attn.log | grep "v1\|v3" | grep "2560\|forward"
+    timeout 200 python tools/norm_bench.py --dtype f32 > $O/norm.log 2>&1; show $O/norm.log | tail -20
+    ;;
+  r4b)         # second call: the pruned library + o_split everywhere + pre-split attention inputs + GroupNorm chunking: correct? faster?
+    ( time timeout 900 python -m pytest tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_kernels_gpu.py tests/test_bf16x3_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error" $O/pytest.log | tail -8
+    timeout 300 python tools/attn_bench.py bf16x3 > $O/attn.log 2>&1; show $O/attn.log | grep "2560\|forward"
+    timeout 200 python tools/norm_bench.py --dtype f32 > $O/norm.log 2>&1; show $O/norm.log | grep unet
+    TAG=$TAG bash $0 retune bf16x3
+    cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-600 $O/bench.json
+    ;;
+  tests)       # gpu test files given as arguments (default: all)
+    ( time timeout 1200 python -m pytest ${@:-tests} -m gpu -q -x --durations=8 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error" $O/pytest.log | tail -8
+    ;;
+  *) echo "unknown job $JOB"; exit 2;;
+esac

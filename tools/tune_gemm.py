@@ -35,6 +35,9 @@ def main():
     changed = sum(1 for k, v in fresh.items() if old.get(k) != v)
     ops._TUNE = {**old, **fresh}
     print(f"re-measured {len(fresh)} shapes, {changed} changed")
+    with open(out + ".log", "w") as f:
+        for key, best, ms, fin in ops.TUNE_LOG:
+            f.write(f"{key} -> t{best[0]}/s{best[1]} {ms * 1e3:.1f} us | was {old.get(key)} | " + "  ".join(f"t{t}/s{s2} {u}" for t, s2, u in fin) + "\n")
     ops.save_tuning(out)
     print("saved", len(ops._tune_table()), "entries to", out)
 
