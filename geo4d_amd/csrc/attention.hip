@@ -357,6 +357,322 @@ __global__ __launch_bounds__(256, OCC) void flash_attn_kernel(const geo4d_attent
     }
 }
 
+// ---- flash_attn2_kernel (round 4): the self-attention loop with the two query blocks of a wave SKEWED by one phase -----------------
+// flash_attn_kernel<.., QB = 2> runs QK^T of both blocks, then both softmaxes, then both P.V: matrix and vector work alternate, and a
+// wave's own MFMAs never have VALU work beside them (measured 27 % bf16 / 31 % bf16x3 of the MFMA peak, unchanged when 30 % of the VALU
+// instructions were removed by the pre-split inputs: the loop is serialised, not issue-bound). Here the per-tile order of ONE wave is
+//     A: S0 = K.Q0^T   |  head0 (row max, lazy rescale)  |  B: S1 = K.Q1^T  beside  P0 = exp2(S0)  |  head1  |
+//     C: O0 += V^T.P0  beside  P1 = exp2(S1)             |  D: O1 += V^T.P1
+// with B and C written as 8 slices of {fragment read for the next MFMA, one MFMA (three for bf16x3), the exponentials / row sums /
+// bf16 conversions (hi / lo split) of 4 scores of the other block}, fenced by sched_barrier(0) so the interleave the source states
+// is the interleave that is issued: the matrix pipe works on a slice's MFMA while the wave issues that slice's ~10-20 VALU
+// instructions. K / V^T fragments are read per block (the shared reads of the QB = 2 build tied both blocks to one phase); masking
+// code for a ragged last key tile is kept out of the full-tile path (hipcc had hoisted its 128 compares into every iteration).
+// One key/value set (nseg == 1), d_head = 64, 16-bit types and bf16x3 (PS: pre-split q / K / V^T as in flash_attn_kernel).
+template <typename T, bool PS, int OCC>
+__global__ __launch_bounds__(256, OCC) void flash_attn2_kernel(const geo4d_attention_t p) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int SLOTS = 64 / EPC;
+    constexpr int ROWB = 64 * ES;
+    constexpr int TILE = 64 * ROWB;
+    constexpr int NDMA = TILE / 1024 / 4;
+    constexpr int RPI = 1024 / ROWB;
+    constexpr bool X3 = IsX3<T>::value;
+    static_assert(ES == 2 || X3, "16-bit types and bf16x3 only");
+    static_assert(!PS || X3, "pre-split inputs are a bf16x3 option");
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];   // [buf][K | Vt]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const T* __restrict__ Z = (const T*)p.zeros;
+    const int nk = p.Nk[0];
+    const int ntile = (nk + 63) >> 6;
+
+    int qrow[2];
+    bool qok[2];
+    u32x4 qf[2][4], ql[2][X3 ? 4 : 1];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qrow[qb] = blockIdx.x * 256 + wave * 64 + qb * 32 + li;
+        qok[qb] = qrow[qb] < p.Nq;
+        const T* qp = (const T*)p.q + ((long)b * p.Nq + (qok[qb] ? qrow[qb] : 0)) * p.ldq + h * 64;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            if constexpr (X3) {
+                u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
+                if (qok[qb]) {
+                    c0 = *(const u32x4*)(qp + (4 * s2 + 2 * g) * EPC);
+                    c1 = *(const u32x4*)(qp + (4 * s2 + 2 * g + 1) * EPC);
+                }
+                if constexpr (PS) { qf[qb][s2] = c0; ql[qb][s2] = c1; }
+                else split8_bf16(c0, c1, qf[qb][s2], ql[qb][s2]);
+            } else {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (qok[qb]) v = *(const u32x4*)(qp + (2 * s2 + g) * EPC);
+                qf[qb][s2] = v;
+            }
+        }
+    }
+    f32x16 oa[2][2];
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oa[qb][d][r] = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;
+    const float thr = 6.0f / c2;                                        // lazy rescale threshold, as in flash_attn_kernel
+
+    // staging geometry (identical to flash_attn_kernel: same LDS image, same source-side swizzle)
+    const int srow = lane / SLOTS, sslot = lane % SLOTS;
+    const T* ksrc[NDMA];
+    const T* vsrc[NDMA];
+    int krow[NDMA], vkey[NDMA];
+    const long kstep = 64 * p.ldk[0];
+    {
+        const long kvb = b / p.kv_div[0];
+        const T* kp = (const T*)p.k[0] + kvb * nk * p.ldk[0] + h * 64;
+        const T* vp = (const T*)p.vt[0] + kvb * p.vt_bs[0] + (long)h * 64 * p.ldvt[0];
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int row = (wave * NDMA + i) * RPI + srow;
+            const int chunk = sslot ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15));
+            krow[i] = row;
+            vkey[i] = PS ? (chunk >> 1) * 8 : chunk * EPC;
+            ksrc[i] = kp + (long)row * p.ldk[0] + chunk * EPC;
+            vsrc[i] = vp + (long)row * p.ldvt[0] + chunk * EPC;
+        }
+    }
+    auto issue_tile = [&](int tile, int buf) {
+        char* kb_ = lds + buf * 2 * TILE;
+        const bool full = tile * 64 + 64 <= nk;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const T* ks = ksrc[i] + (long)tile * kstep;
+            const T* vs = vsrc[i] + tile * 64;
+            if (!full) {
+                if (tile * 64 + krow[i] >= nk) ks = Z;
+                if (tile * 64 + vkey[i] >= nk) vs = Z;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                             (__attribute__((address_space(3))) void*)(kb_ + (wave * NDMA + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                             (__attribute__((address_space(3))) void*)(kb_ + TILE + (wave * NDMA + i) * 1024), 16, 0, 0);
+        }
+    };
+    const int swz = ES == 2 ? ((li >> 1) & 7) : (li & 15);
+
+// fragment reads: K step s (16 d) of key block kb; V^T for keys of P chunk (kb, c) and channel block d (layouts: flash_attn_kernel)
+#define A2_READ_K(KT, KB, S, FH, FL)                                                                   \
+    do {                                                                                               \
+        const char* krow_ = (KT) + ((KB) * 32 + li) * ROWB;                                            \
+        if constexpr (X3) {                                                                            \
+            const u32x4 c0_ = *(const u32x4*)(krow_ + (((4 * (S) + 2 * g) ^ swz) << 4));               \
+            const u32x4 c1_ = *(const u32x4*)(krow_ + (((4 * (S) + 2 * g + 1) ^ swz) << 4));           \
+            if constexpr (PS) { FH = c0_; FL = c1_; }                                                  \
+            else split8_bf16(c0_, c1_, FH, FL);                                                        \
+        } else {                                                                                       \
+            FH = *(const u32x4*)(krow_ + (((2 * (S) + g) ^ swz) << 4));                                \
+        }                                                                                              \
+    } while (0)
+#define A2_READ_V(VT, KB, CC, D, FH, FL)                                                               \
+    do {                                                                                               \
+        const char* vrow_ = (VT) + ((D) * 32 + li) * ROWB;                                             \
+        if constexpr (X3 && PS) {                                                                      \
+            const u32x2 h0_ = *(const u32x2*)(vrow_ + (((8 * (KB) + 4 * (CC)) ^ swz) << 4) + 8 * g);     \
+            const u32x2 l0_ = *(const u32x2*)(vrow_ + (((8 * (KB) + 4 * (CC) + 1) ^ swz) << 4) + 8 * g); \
+            const u32x2 h1_ = *(const u32x2*)(vrow_ + (((8 * (KB) + 4 * (CC) + 2) ^ swz) << 4) + 8 * g); \
+            const u32x2 l1_ = *(const u32x2*)(vrow_ + (((8 * (KB) + 4 * (CC) + 3) ^ swz) << 4) + 8 * g); \
+            FH = u32x4{h0_[0], h0_[1], h1_[0], h1_[1]};                                                \
+            FL = u32x4{l0_[0], l0_[1], l1_[0], l1_[1]};                                                \
+        } else if constexpr (X3) {                                                                     \
+            const u32x4 c0_ = *(const u32x4*)(vrow_ + (((8 * (KB) + 4 * (CC) + g) ^ swz) << 4));       \
+            const u32x4 c1_ = *(const u32x4*)(vrow_ + (((8 * (KB) + 4 * (CC) + 2 + g) ^ swz) << 4));   \
+            split8_bf16(c0_, c1_, FH, FL);                                                             \
+        } else {                                                                                       \
+            const u32x2 lo_ = *(const u32x2*)(vrow_ + (((4 * (KB) + 2 * (CC)) ^ swz) << 4) + 8 * g);   \
+            const u32x2 hi_ = *(const u32x2*)(vrow_ + (((4 * (KB) + 2 * (CC) + 1) ^ swz) << 4) + 8 * g); \
+            FH = u32x4{lo_[0], lo_[1], hi_[0], hi_[1]};                                                \
+        }                                                                                              \
+    } while (0)
+#define A2_MMA(ACC, AH, AL, BH, BL)                                  \
+    do {                                                             \
+        if constexpr (X3) mma_x3(ACC, AH, AL, BH, BL);               \
+        else cmma<T>(ACC, AH, BH);                                   \
+    } while (0)
+// exponentials of scores 4 j .. 4 j + 3 of key block kb (slice I = 4 kb + j) -> words 2 (j & 1), + 1 of P chunk (kb, j >> 1); row sums
+#define A2_EXP_SLICE(ST, PH, PL, LS, I)                                                                \
+    do {                                                                                               \
+        constexpr int kb_ = (I) >> 2, j_ = (I) & 3, c_ = j_ >> 1, w_ = 2 * (j_ & 1);                   \
+        f32x2 x0_ = {ST[kb_][4 * j_], ST[kb_][4 * j_ + 1]}, x1_ = {ST[kb_][4 * j_ + 2], ST[kb_][4 * j_ + 3]}; \
+        x0_ = __builtin_elementwise_fma(x0_, c2v, mcv);                                                \
+        x1_ = __builtin_elementwise_fma(x1_, c2v, mcv);                                                \
+        x0_[0] = __builtin_amdgcn_exp2f(x0_[0]);                                                       \
+        x0_[1] = __builtin_amdgcn_exp2f(x0_[1]);                                                       \
+        x1_[0] = __builtin_amdgcn_exp2f(x1_[0]);                                                       \
+        x1_[1] = __builtin_amdgcn_exp2f(x1_[1]);                                                       \
+        LS[0] += x0_[0];                                                                               \
+        LS[1] += x0_[1];                                                                               \
+        LS[0] += x1_[0];                                                                               \
+        LS[1] += x1_[1];                                                                               \
+        /* the empty asm pins the results HERE: without it LLVM sinks the whole slice next to its first use (the P.V phase) */ \
+        if constexpr (X3) {                                                                            \
+            unsigned int h0_ = f32x2_to_bf16x2(x0_[0], x0_[1]), h1_ = f32x2_to_bf16x2(x1_[0], x1_[1]); \
+            unsigned int l0_ = f32x2_to_bf16x2(x0_[0] - __uint_as_float(h0_ << 16), x0_[1] - __uint_as_float(h0_ & 0xffff0000u)); \
+            unsigned int l1_ = f32x2_to_bf16x2(x1_[0] - __uint_as_float(h1_ << 16), x1_[1] - __uint_as_float(h1_ & 0xffff0000u)); \
+            asm volatile("" : "+v"(h0_), "+v"(h1_), "+v"(l0_), "+v"(l1_), "+v"(LS[0]), "+v"(LS[1]));   \
+            PH[kb_][c_][w_] = h0_;                                                                     \
+            PH[kb_][c_][w_ + 1] = h1_;                                                                 \
+            PL[kb_][c_][w_] = l0_;                                                                     \
+            PL[kb_][c_][w_ + 1] = l1_;                                                                 \
+        } else {                                                                                       \
+            unsigned int h0_, h1_;                                                                     \
+            if constexpr (Elem<T>::DT == GEO4D_BF16) { h0_ = f32x2_to_bf16x2(x0_[0], x0_[1]); h1_ = f32x2_to_bf16x2(x1_[0], x1_[1]); } \
+            else { h0_ = f32x2_to_f16x2(x0_[0], x0_[1]); h1_ = f32x2_to_f16x2(x1_[0], x1_[1]); }      \
+            asm volatile("" : "+v"(h0_), "+v"(h1_), "+v"(LS[0]), "+v"(LS[1]));                         \
+            PH[kb_][c_][w_] = h0_;                                                                     \
+            PH[kb_][c_][w_ + 1] = h1_;                                                                 \
+        }                                                                                              \
+    } while (0)
+
+    // row max of one block's 64 scores, the lazy-rescale decision (T13 order: the block's previous P.V is complete - it is the
+    // producer of oa - and this tile's P is formed only afterwards), the exponent's fma constants
+    auto head = [&](f32x16 (&st)[2], f32x16 (&o)[2], float& m, float& l, int tile, f32x2& mcv) {
+        if (tile * 64 + 64 > nk) {
+            int t0 = tile * 64 + 4 * g, nko = nk;
+            asm volatile("" : "+v"(t0), "+s"(nko));      // opaque: keeps the 64 compares (and their lane constants) of the ragged tile out of the full-tile path
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t0 + kb * 32 + acc_row(r, 0) >= nko) st[kb][r] = -INFINITY;
+        }
+        float mt = st[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; r += 2)
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[0][r]), "v"(st[0][r + 1 < 16 ? r + 1 : r]));
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mt) : "v"(mt), "v"(st[1][r]), "v"(st[1][r + 1]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        if (__any(mt > m + thr)) {
+            const float m_new = fmaxf(m, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c2);
+            l *= alpha;
+            m = m_new;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        mcv = f32x2{-m * c2, -m * c2};
+    };
+    const f32x2 c2v = {c2, c2};
+
+    int buf = 0;
+    issue_tile(0, 0);
+    for (int tile = 0; tile < ntile; ++tile, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is invisible to hipcc's waitcnt insertion: drain, THEN barrier
+        __syncthreads();
+        if (tile + 1 < ntile) issue_tile(tile + 1, buf ^ 1);
+        const char* ktile = lds + buf * 2 * TILE;
+        const char* vtile = ktile + TILE;
+        f32x16 s0[2], s1[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[kb][r] = 0.f; s1[kb][r] = 0.f; }
+        u32x4 ph0[2][2], pl0[2][X3 ? 2 : 1], ph1[2][2], pl1[2][X3 ? 2 : 1];
+        u32x4 fh[3], fl[3];
+        f32x2 mcv;
+        // ---- A: S0 = K.Q0^T (slice i: key block i & 1, k-step i >> 1: the two accumulators alternate) -----------------------------
+        // (fragments are requested two slices ahead through a 3-slot register ring: fragment i sits in slot i % 3)
+        A2_READ_K(ktile, 0, 0, fh[0], fl[0]);
+        A2_READ_K(ktile, 1, 0, fh[1], fl[1]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < 6) A2_READ_K(ktile, (i + 2) & 1, (i + 2) >> 1, fh[(i + 2) % 3], fl[(i + 2) % 3]);
+            A2_MMA(s0[i & 1], fh[i % 3], fl[i % 3], qf[0][i >> 1], ql[0][X3 ? (i >> 1) : 0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        head(s0, oa[0], m_run[0], l_run[0], tile, mcv);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- B: S1 = K.Q1^T beside P0 = exp2(S0 c - m c) ---------------------------------------------------------------------------
+        {
+            float ls[2] = {0.f, 0.f};
+            A2_READ_K(ktile, 0, 0, fh[0], fl[0]);
+            A2_READ_K(ktile, 1, 0, fh[1], fl[1]);
+#define A2_B_SLICE(I)                                                                                                  \
+            if ((I) < 6) A2_READ_K(ktile, ((I) + 2) & 1, ((I) + 2) >> 1, fh[((I) + 2) % 3], fl[((I) + 2) % 3]);        \
+            A2_MMA(s1[(I) & 1], fh[(I) % 3], fl[(I) % 3], qf[1][(I) >> 1], ql[1][X3 ? ((I) >> 1) : 0]);                \
+            A2_EXP_SLICE(s0, ph0, pl0, ls, I);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);
+            A2_B_SLICE(0) A2_B_SLICE(1) A2_B_SLICE(2) A2_B_SLICE(3) A2_B_SLICE(4) A2_B_SLICE(5) A2_B_SLICE(6) A2_B_SLICE(7)
+#undef A2_B_SLICE
+            l_run[0] += ls[0] + ls[1];
+        }
+        head(s1, oa[1], m_run[1], l_run[1], tile, mcv);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C: O0 += V^T.P0 beside P1 = exp2(S1 c - m c) (slice i: P chunk (i >> 2, (i >> 1) & 1), channel block i & 1) ------------
+        {
+            float ls[2] = {0.f, 0.f};
+            A2_READ_V(vtile, 0, 0, 0, fh[0], fl[0]);
+            A2_READ_V(vtile, 0, 0, 1, fh[1], fl[1]);
+#define A2_C_SLICE(I)                                                                                                  \
+            if ((I) < 6) A2_READ_V(vtile, ((I) + 2) >> 2, (((I) + 2) >> 1) & 1, ((I) + 2) & 1, fh[((I) + 2) % 3], fl[((I) + 2) % 3]); \
+            A2_MMA(oa[0][(I) & 1], fh[(I) % 3], fl[(I) % 3], ph0[(I) >> 2][((I) >> 1) & 1], pl0[(I) >> 2][X3 ? (((I) >> 1) & 1) : 0]); \
+            A2_EXP_SLICE(s1, ph1, pl1, ls, I);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);
+            A2_C_SLICE(0) A2_C_SLICE(1) A2_C_SLICE(2) A2_C_SLICE(3) A2_C_SLICE(4) A2_C_SLICE(5) A2_C_SLICE(6) A2_C_SLICE(7)
+#undef A2_C_SLICE
+            l_run[1] += ls[0] + ls[1];
+        }
+        // ---- D: O1 += V^T.P1 ----------------------------------------------------------------------------------------------------------
+        A2_READ_V(vtile, 0, 0, 0, fh[0], fl[0]);
+        A2_READ_V(vtile, 0, 0, 1, fh[1], fl[1]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < 6) A2_READ_V(vtile, (i + 2) >> 2, ((i + 2) >> 1) & 1, (i + 2) & 1, fh[(i + 2) % 3], fl[(i + 2) % 3]);
+            A2_MMA(oa[1][i & 1], fh[i % 3], fl[i % 3], ph1[i >> 2][(i >> 1) & 1], pl1[i >> 2][X3 ? ((i >> 1) & 1) : 0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef A2_READ_K
+#undef A2_READ_V
+#undef A2_MMA
+#undef A2_EXP_SLICE
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float lt = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        const float inv = 1.0f / lt;
+        if (!qok[qb]) continue;
+        T* op = (T*)p.o + ((long)b * p.Nq + qrow[qb]) * p.ldo + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dcol = d * 32 + 8 * i + 4 * g;
+                if constexpr (ES == 2) {
+                    float e[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { e[j] = oa[qb][d][4 * i + j] * inv; e[4 + j] = 0.f; }
+                    const u32x4 c = f32_to_chunk<T>(e);
+                    u32x2 o2; o2[0] = c[0]; o2[1] = c[1];
+                    *(u32x2*)(op + dcol) = o2;
+                } else {
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = oa[qb][d][4 * i + j] * inv;
+                    if (p.split_out) store_split4(op - h * 64, (h * 64 + dcol) >> 2, e);
+                    else *(u32x4*)(op + dcol) = f32_to_chunk<T>(e);
+                }
+            }
+    }
+}
+
 // one wave per (batch, pixel, head); lane = (query frame tq = lane >> 2, d-slice dp = lane & 3 of 16 channels).
 // Q, K, V of the unit are staged as fp32 in LDS; the d-slice is walked in 4-wide steps by a ROLLED loop so the
 // kernel stays at ~64 VGPRs (a fully unrolled body made hipcc hoist all 128 ds_read_b128 and spill).
@@ -490,7 +806,25 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     // variant: 0 = host default; explicit: 1 = 128 rows / workgroup at 3 waves per SIMD (round-1 kernel), 2 = the same at 4 waves
     // per SIMD (128-VGPR budget), 3 = 256 rows / workgroup, two query blocks per wave (self-attention only)
     int variant = p.variant;
-    if (variant < 0 || variant > 3) { geo4d_set_error("attention: unknown variant"); return GEO4D_EINVAL; }
+    if (variant < 0 || variant > 5) { geo4d_set_error("attention: unknown variant"); return GEO4D_EINVAL; }
+    // 4 / 5 = flash_attn2_kernel (round 4: skewed query blocks, matrix work beside every softmax): one key/value set, 16-bit types
+    // (4) and bf16x3 on pre-split inputs (4 = one wave per SIMD with the whole register file, 5 = two waves per SIMD).
+    // Default since round 4 wherever it applies and a 256-row workgroup is not mostly empty (measured, profiles/r04_attention.md:
+    // bf16 N = 2560 199.9 -> 194.7 us, N = 640 33.6 -> 32.8; pre-split bf16x3 N = 2560 524 -> 474 us, N = 640 76.3 -> 70.7)
+    if (variant == 0 && p.nseg == 1 && p.Nq >= 256 &&
+        (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16 || (p.dtype == GEO4D_BF16X3 && p.qkv_split))) variant = 4;
+    if (variant >= 4) {
+        const bool ok16 = (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16) && variant == 4;
+        const bool okx3 = p.dtype == GEO4D_BF16X3 && p.qkv_split;
+        if (p.nseg != 1 || !(ok16 || okx3)) { geo4d_set_error("attention: variants 4 / 5 take one key/value set in bf16 / f16 (4) or pre-split bf16x3"); return GEO4D_EINVAL; }
+        const dim3 grid2((p.Nq + 255) / 256, p.H, p.B);
+        if (p.dtype == GEO4D_BF16) hipLaunchKernelGGL((flash_attn2_kernel<bf16_t, false, 2>), grid2, dim3(256), 0, st, p);
+        else if (p.dtype == GEO4D_F16) hipLaunchKernelGGL((flash_attn2_kernel<f16_t, false, 2>), grid2, dim3(256), 0, st, p);
+        else if (variant == 4) hipLaunchKernelGGL((flash_attn2_kernel<bf16x3_t, true, 1>), grid2, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((flash_attn2_kernel<bf16x3_t, true, 2>), grid2, dim3(256), 0, st, p);
+        GEO4D_CHECK_LAUNCH();
+        return GEO4D_OK;
+    }
     // default (measured, profiles/r02_attention_variants.md): two query blocks per wave for 16-bit self-attention (bf16 N = 2560:
     // 245 -> 199 us), one for the 4-byte storage modes (their two-block build spills: bf16x3 523 -> 563 us)
     if (variant == 0) variant = (p.nseg == 1 && (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16)) ? 3 : 1;

@@ -585,7 +585,9 @@ int launch_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     if (p.tile_hint >= 21) return launch_v2_typed<T>(p, stream);
     if (p.o_split) {     // the pre-split output format lives in the register epilogue of the second-generation kernel only
         geo4d_conv_gemm_t q = p;
-        q.tile_hint = (p.tile_hint == 13 || p.tile_hint == 11) ? 22 : p.tile_hint == 16 ? 23 : p.tile_hint == 3 ? 27 : p.tile_hint == 4 ? 28 : 25;
+        // (GEGLU needs wave tiles that are a multiple of 64 columns wide: 22, 25, 27 of the second generation)
+        const bool gg = p.act == 2;
+        q.tile_hint = (p.tile_hint == 13 || p.tile_hint == 11) ? 22 : p.tile_hint == 16 ? (gg ? 22 : 23) : p.tile_hint == 3 ? 27 : p.tile_hint == 4 ? (gg ? 27 : 28) : 25;
         return launch_v2_typed<T>(q, stream);
     }
     if (p.tile_hint >= 11) {

@@ -228,7 +228,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         assert rowbias.dtype == torch.float32 and rowbias.dim() == 2 and rowbias.stride(1) == 1
         p.ldrb = rowbias.stride(0)
     if residual is not None:
-        assert residual.dtype == out.dtype
+        assert residual.dtype == (torch.float32 if isinstance(out, SplitAct) else out.dtype)      # (a SplitAct is f32 values in bf16 storage)
     p.lda, p.ldw, p.ldo, p.ldr = lda, ldw, ldo, ldr
     p.a_bs, p.w_bs, p.o_bs, p.r_bs = a_bs, w_bs, o_bs, r_bs
     p.M, p.N, p.K, p.batch, p.Cin = M, N, K, batch, Cin
@@ -259,7 +259,11 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         if cfg is None and code == BF16X3 and a_split and w_split:
             # pre-split activations: same tile geometry as the raw-activation launch of the same shape (table measured on those)
             base = key.split("|x")[0]
-            cfg = _tune_table().get(base + "|x01") or _tune_table().get(base + "|x10")
+            cfg = (_tune_table().get(base + "|x11") if p.o_split else None) or _tune_table().get(base + "|x01") or _tune_table().get(base + "|x10")
+            if cfg is not None and p.o_split and cfg[1] > 1:
+                # the pre-split output has no split-K form (the reduce kernel writes plain f32): measure this launch on its own when
+                # that is allowed, else keep the tile and drop the split
+                cfg = None if (AUTOTUNE and not torch.cuda.is_current_stream_capturing()) else (cfg[0], 1)
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)

@@ -139,7 +139,10 @@ typedef struct geo4d_attention_t {
     int split_out;       /* 4-byte storage only (dtype F32 or BF16X3 - the bf16x3 mode stores its activations as f32): o is written in the pre-split operand format of geo4d_conv_gemm_t.a_split (ldo still
                             counts channels) - the to_out projection consumes it without splitting again */
     int variant;         /* 0 = default; A/B builds of the same math: 1 = 128 query rows per workgroup, 2 = the same compiled for
-                            4 waves per SIMD (16-bit types), 3 = 256 rows per workgroup, two query blocks per wave (nseg == 1) */
+                            4 waves per SIMD (16-bit types), 3 = 256 rows per workgroup, two query blocks per wave (nseg == 1),
+                            4 = 256 rows per workgroup with the two blocks' phases skewed so every softmax has the other block's MFMAs
+                            beside it (nseg == 1; bf16 / f16, and bf16x3 with qkv_split at one wave per SIMD), 5 = the bf16x3 form of 4
+                            at two waves per SIMD */
     int qkv_split;       /* dtype 3 (bf16x3), nseg == 1 only: q, k[0] and vt[0] are stored in the PRE-SPLIT operand format (written by
                             geo4d_conv_gemm_t.o_split projections): per 8 elements of a row [8 x bf16 hi | 8 x bf16 lo]; ld* / vt_bs still
                             count 4-byte elements and must be multiples of 8, bases 32-byte aligned, Nk % 8 == 0. Same results, bit

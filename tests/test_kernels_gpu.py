@@ -236,12 +236,14 @@ def test_attention_self(dev, dtype, N):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [1, 2, 3])
-@pytest.mark.parametrize("N", [200, 640, 2560])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("N", [40, 200, 640, 2560])
 def test_attention_variants(dev, dtype, variant, N):
     """The A/B builds of the flash kernel (geo4d_attention_t.variant: 4-waves-per-SIMD build, two query blocks per wave with
     256-row workgroups — ragged N = 200 leaves one block half empty) compute the same attention."""
     from geo4d_amd import ops
+    if variant == 4 and dtype == torch.float32:
+        pytest.skip("variant 4 (flash_attn2_kernel, skewed query blocks) is built for the 16-bit types and pre-split bf16x3")
     B, H = 2, 3
     C_ = H * 64
     qkv = rnd((B * N, 3 * C_), dev, dtype, 130 + N)
@@ -296,6 +298,10 @@ def test_attention_online_softmax_rescale(dev, dtype):
     k[200] = (q[7].float() * 4).to(dtype)
     out = ops.attention(q, [(k, _vt(v, 1, N), N, 1, N)], B=1, H=H, Nq=N, scale=0.125)
     check("attn spike", out, _sdpa(q.float(), k.float(), v.float(), 0.125), dtype, scale=2.0)
+    if dtype != torch.float32:         # the skewed-block kernel: the spiked row sits in the wave's FIRST query block, a second spike in its second block
+        k[130] = (q[40].float() * 4).to(dtype)
+        out = ops.attention(q, [(k, _vt(v, 1, N), N, 1, N)], B=1, H=H, Nq=N, scale=0.125, variant=4)
+        check("attn spike (variant 4)", out, _sdpa(q.float(), k.float(), v.float(), 0.125), dtype, scale=2.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

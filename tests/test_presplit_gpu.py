@@ -191,6 +191,10 @@ def test_plain_epilogue_split_output(dev, tile):
         split = ops.linear(xs, wp, b, tile_hint=tile, split_out=True, **kw)
         assert isinstance(split, ops.SplitAct) and split.shape == (M, 2 * N)
         hi, lo = decode_split(split)
+        if tile < 20:      # tile 0: table / tuner pick per launch signature; first-generation hints: the split output is re-routed to the
+            # second-generation twin (16x16x32 MFMA instead of 32x32x16): the two launches associate the fp32 sums differently
+            assert ((hi + lo) - plain).abs().max().item() < 2e-5 * plain.abs().max().item(), f"tile {tile} {list(kw)}"
+            continue
         want_hi = plain.to(torch.bfloat16).float()
         assert torch.equal(hi, want_hi), f"tile {tile} {list(kw)}: hi"
         assert torch.equal(lo, (plain - want_hi).to(torch.bfloat16).float()), f"tile {tile} {list(kw)}: lo"
@@ -223,6 +227,12 @@ def test_spatial_attention_on_presplit_qkv_equals_raw(dev):
                 check_split(f"attention qkv_split F{F} N{N}", pre, raw)
             else:
                 assert torch.equal(pre, raw), f"F{F} N{N}: {((pre - raw).norm() / raw.norm()).item():.3e}"
+        for variant in (4, 5):      # flash_attn2_kernel (skewed query blocks; one / two waves per SIMD): same sums in the same order per accumulator
+            pre = ops.attention(qks[:, :2 * C], [(qks[:, 2 * C:], vts.reshape(-1, 2 * npad2), N, 1, C * 2 * npad2)], B=F, H=H, Nq=N,
+                                scale=0.125, x3=True, qkv_split=True, variant=variant)
+            e = ((pre - raw).norm() / raw.norm()).item()
+            print(f"[attention qkv_split variant {variant} F{F} N{N}] vs the first-generation kernel: rel_l2 = {e:.2e}, equal = {torch.equal(pre, raw)}")
+            assert e < 2e-6, (variant, F, N, e)
         q, k = qk[:, :C].reshape(F, N, H, 64).permute(0, 2, 1, 3), qk[:, C:].reshape(F, N, H, 64).permute(0, 2, 1, 3)
         v = vt.reshape(F, H, 64, npad)[..., :N].permute(0, 1, 3, 2)
         ref = TF.scaled_dot_product_attention(q.double(), k.double(), v.double()).permute(0, 2, 1, 3).reshape(F * N, C).float()

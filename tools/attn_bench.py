@@ -10,10 +10,10 @@ for name in (sys.argv[1:] or ["bf16"]):
     x3 = name == "bf16x3"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "bf16x3": torch.float32}[name]
     passes = 3 if x3 else 1
-    for variant in (1, 2, 3, "1ps", "3ps"):
+    for variant in (1, 2, 3, 4, "1ps", "3ps", "4ps", "5ps"):
         ps = isinstance(variant, str)                  # bf16x3 only: q | k and V^T in the producers' pre-split format (qkv_split, round 4)
-        if (variant == 2 and dt == torch.float32) or (ps and not x3):
-            continue
+        if (variant == 2 and dt == torch.float32) or (ps and not x3) or (variant == 4 and dt == torch.float32):
+            continue                                   # 4 / 5 = flash_attn2_kernel (round 4): 16-bit types and pre-split bf16x3 only
         vnum = int(variant[0]) if ps else variant
         tot_ms = 0
         for F_, H, N, cnt in LEVELS:

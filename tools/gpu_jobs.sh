@@ -46,6 +46,25 @@ case $JOB in
     cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
     timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-600 $O/bench.json
     ;;
+  r4c)         # re-entry call: the groundwork commit on the GPU (tests of the touched kernels), census with every candidate + vendor bound, attention / norm benches, bench line
+    ( time timeout 700 python -m pytest tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_kernels_gpu.py tests/test_bf16x3_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error" $O/pytest.log | tail -8
+    timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-900 $O/bench.json
+    TAG=$TAG bash $0 census bf16x3
+    timeout 300 python tools/attn_bench.py bf16 bf16x3 > $O/attn.log 2>&1; show $O/attn.log | grep "2560\|forward"
+    timeout 200 python tools/norm_bench.py --dtype f32 > $O/norm.log 2>&1; show $O/norm.log | grep "unet\|L[012]"
+    ;;
+  r4d)         # the skewed-block attention kernel (variants 4 / 5): correct? faster?  + the o_split table fallback fix under the bench
+    ( time timeout 600 python -m pytest tests/test_presplit_gpu.py tests/test_kernels_gpu.py tests/test_bf16x3_gpu.py -m gpu -q -x -k "attention or presplit or split" --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error|variant" $O/pytest.log | tail -12
+    timeout 300 python tools/attn_bench.py bf16 bf16x3 > $O/attn.log 2>&1; show $O/attn.log | grep "2560\|forward\| 640"
+    timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-1200 $O/bench.json
+    ;;
+  r4e)         # after the o_split fixes + variant 4 as the attention default: the touched tests, then the bench line
+    ( time timeout 900 python -m pytest tests/test_presplit_gpu.py tests/test_kernels_gpu.py tests/test_bf16x3_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error|variant" $O/pytest.log | tail -12
+    timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-1500 $O/bench.json
+    ;;
   tests)       # gpu test files given as arguments (default: all)
     ( time timeout 1200 python -m pytest ${@:-tests} -m gpu -q -x --durations=8 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
     grep -E "passed|failed|rc=|Error" $O/pytest.log | tail -8
