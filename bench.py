@@ -142,7 +142,10 @@ def cpu_baseline(model, pvae, ddim_steps, T, h, w, budget_s=240):
                       f"convs / einsums slower) ({note}): 1 timed U-Net forward at 1x20x{T}x{h}x{w} ({t_unet:.1f} s) + 1 timed "
                       f"conf-decode frame at 1x4x{h}x{w} -> {8 * h}x{8 * w} ({t_dec:.1f} s), after a small warm-up forward; window = "
                       f"{ddim_steps} forwards + {4 * T} frame decodes = {t_window:.0f} s (the 3 plain decodes are counted at the conf-decode "
-                      "cost: <= 3 % high)"}
+                      "cost: <= 3 % high)",
+            "calibration": "port vs reference on one host (build container, 8 threads, same weights / inputs, profiles/r04_cpu_baseline_crosscheck.md): "
+                           "the oracle takes 0.86x the wall time of the imported reference classes (U-Net forward 31.4 s vs 37.4 s, conf-decode frame "
+                           "2.7 s vs 2.4 s), i.e. this value overstates the reference's own CPU rate by ~1.16x"}
 
 
 def gemm_timeline(model, x_T, cond, fs, dev):
