@@ -45,6 +45,14 @@ template <typename T> __device__ __forceinline__ int swz_key(int row) {
 // ---- register epilogue shared by the second- and third-generation kernels: acc[a][b][j] is out[m_w0 + 16a + lr][n_w0 + 16b + 4lq + j]
 // (bias / row-bias / activation / GEGLU / residual / rounding in registers, 16-byte (f32) or 8-byte (16-bit) stores). `partial`:
 // split-K launch, the raw fp32 slab of split e_kz goes to the workspace and the epilogue runs in splitk_reduce_kernel.
+// Round 4 - fast paths for 4-byte rows (every bf16x3 projection / conv except the ResBlocks' emb-add convs and the per-row-bias V^T
+// projections). tools/gemm_kscan.py measured a K-INDEPENDENT ~30 us per tile in these kernels (profiles/r04_gemm_kscan.md: 97 us of a
+// 151 us level-0 qkv launch): the generic code below loads bias / residual element by element behind per-element branches, each load
+// followed by s_waitcnt vmcnt(0) - and vmcnt is in order over loads AND stores, so every block's loads waited until the previous
+// block's stores were acknowledged (~1.3 us x 24-25 blocks per tile). The fast paths have no per-element branches: the column bias
+// is ONE 16-byte load per block outside the row loop, the residual one 16-byte load issued a row block AHEAD of the stores (counted
+// wait), and the pre-split output is written as whole 16-byte hi / lo chunks (the two lanes of an 8-column group trade their halves
+// with v_permlane16_swap) instead of two 8-byte pieces per lane. Same values, same addresses.
 template <int MB, int NB, bool OSPLIT, bool VECONLY = false>   // VECONLY: the host checked the vector-store conditions (no scalar fallback code)
 __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f32x4 (&acc)[MB][NB], const int m_w0, const int n_w0,
                                              const long e_bz, const int e_kz, const bool partial, const int lr, const int lq) {
@@ -60,6 +68,94 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
     // 4-element vectors need 4-element aligned rows and bases (16 B for f32, 8 B for 16-bit outputs)
     const bool vec_ok = VECONLY || ((nout & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)O + obase * oesz) % (4 * oesz)) == 0 &&
                                     (!has_res || ((p.ldr & 3) == 0 && (((uintptr_t)p.R + rbase * oesz) % (4 * oesz)) == 0)));
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    // this lane's 16-byte chunk `lq` of a block's 64 output bytes (4-byte rows)
+    auto chunk_of = [&](const float (&e)[4]) __attribute__((always_inline)) -> u32x4 {
+        if constexpr (OSPLIT) {
+            const unsigned int h0 = f32x2_to_bf16x2(e[0], e[1]), h1 = f32x2_to_bf16x2(e[2], e[3]);
+            const unsigned int l0 = f32x2_to_bf16x2(e[0] - __uint_as_float(h0 << 16), e[1] - __uint_as_float(h0 & 0xffff0000u));
+            const unsigned int l1 = f32x2_to_bf16x2(e[2] - __uint_as_float(h1 << 16), e[3] - __uint_as_float(h1 & 0xffff0000u));
+            // rows of 16 lanes = lq: odd rows of (h) <-> even rows of (l): even lq ends with [h own | h of lq + 1] = the group's hi chunk,
+            // odd lq with [l of lq - 1 | l own] = its lo chunk (every lane of the wave takes part: no divergence before this point)
+            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
+            return u32x4{s0[0], s1[0], s0[1], s1[1]};
+        } else {
+            return u32x4{__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
+        }
+    };
+    const bool wide = vec_ok && odt == GEO4D_F32;       // (o_split: N % 8 == 0, so the two lanes of an 8-column group are in range together)
+    // Fast paths: every access goes through a raw buffer resource whose base is this wave's tile corner (wave-uniform, SGPRs): a lane
+    // outside M x N offers an offset beyond the 2 GB window (stores dropped, loads return 0 - no exec-masked branches, so hipcc's
+    // waits stay COUNTED), an absent bias / residual is a resource with zero records (its loads return 0 without touching memory).
+    constexpr unsigned OOB = 0x80000000u;
+    auto uniform_ptr = [](const void* q) __attribute__((always_inline)) -> void* {
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    if (wide && !geglu && (partial || (p.act == 0 && !p.rowbias && !(p.bias && p.bias_per_row)))) {
+        const float alpha = partial ? 1.0f : p.alpha;
+        const bool hb = !partial && p.bias != nullptr;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((float*)O + obase + (long)m_w0 * ldo + n_w0), 0, OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(has_res ? (const void*)((const float*)p.R + rbase + (long)m_w0 * p.ldr + n_w0) : p.zeros), 0, has_res ? OOB : 0u, 0x00020000);
+        const int nleft = p.N - n_w0;
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(hb ? (const void*)(p.bias + n_w0) : p.zeros), 0, (hb && nleft > 0) ? (unsigned)nleft * 4u : 0u, 0x00020000);
+        const unsigned offO = (unsigned)(lr * (int)ldo + 4 * lq) * 4u, offR = (unsigned)(lr * (int)p.ldr + 4 * lq) * 4u;
+        const unsigned rowO = (unsigned)ldo * 64u, rowR = (unsigned)p.ldr * 64u;       // bytes per 16-row block
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const bool colok = n_w0 + 16 * b + 4 * lq < p.N;
+            const u32x4 bcu = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b, 0, 0);
+            u32x4 ru = __builtin_amdgcn_raw_buffer_load_b128(rsR, ((colok && m_w0 + lr < p.M) ? offR : OOB) + 64u * b, 0, 0);
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const bool ok = colok && m_w0 + a * 16 + lr < p.M;
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = (acc[a][b][j] * alpha + __uint_as_float(bcu[j])) + __uint_as_float(ru[j]);
+                const u32x4 c = chunk_of(e);
+                if (a + 1 < MB)              // the next row block's residual goes out BEFORE this block's store: its wait stays counted
+                    ru = __builtin_amdgcn_raw_buffer_load_b128(rsR, ((colok && m_w0 + (a + 1) * 16 + lr < p.M) ? offR : OOB) + 64u * b, (a + 1) * rowR, 0);
+                // (row-block offset in the VGPR offset, soffset = 0: with an SGPR soffset hipcc's hazard recognizer assumes a 16-byte buffer
+                // store's data registers may be overwritten right away - on gfx950 the last lanes of every 16 then stored the NEXT block's
+                // values, tools/dbg_epilogue.py; measured round 4)
+                __builtin_amdgcn_raw_buffer_store_b128(c, rsO, (ok ? offO + a * rowO : OOB) + 64u * b, 0, 0);
+            }
+        }
+        return;
+    }
+    if (wide && geglu) {             // bias (value | gate columns) once per block, outside the row loop; only stores inside
+        if constexpr (NB % 4 == 0) {
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((float*)O + obase + (long)m_w0 * ldo + (n_w0 >> 1)), 0, OOB, 0x00020000);
+            const int nleft = p.N - n_w0;
+            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_ptr(p.bias ? (const void*)(p.bias + n_w0) : p.zeros), 0, (p.bias && nleft > 0) ? (unsigned)nleft * 4u : 0u, 0x00020000);
+            const unsigned offO = (unsigned)(lr * (int)ldo + 4 * lq) * 4u, rowO = (unsigned)ldo * 64u;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if ((b & 3) >= 2) continue;
+                // whole 64-column value | gate groups only (N % 64 == 0): wave-uniform, folded into the store offset
+                const bool grp = n_w0 + 16 * (b & ~3) + 64 <= p.N;
+                const u32x4 bv = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b, 0, 0);
+                const u32x4 bg = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b + 128u, 0, 0);
+#pragma unroll
+                for (int a = 0; a < MB; ++a) {
+                    const bool ok = grp && m_w0 + a * 16 + lr < p.M;
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        e[j] = (acc[a][b][j] * p.alpha + __uint_as_float(bv[j])) * gelu_erf_f(acc[a][b + 2 < NB ? b + 2 : b][j] * p.alpha + __uint_as_float(bg[j]));
+                    const u32x4 c = chunk_of(e);
+                    __builtin_amdgcn_raw_buffer_store_b128(c, rsO, (ok ? offO + a * rowO : OOB) + (unsigned)(32 * (b >> 2) + 16 * (b & 1)) * 4u, 0, 0);
+                }
+            }
+        }
+        return;
+    }
+    // ---- generic path (activations, row-bias tables, per-row bias, 16-bit rows, unaligned rows): element by element ----------------
 #pragma unroll
     for (int a = 0; a < MB; ++a) {
         const int m = m_w0 + a * 16 + lr;

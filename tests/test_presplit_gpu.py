@@ -219,14 +219,16 @@ def test_spatial_attention_on_presplit_qkv_equals_raw(dev):
         vts, npad2 = ops.linear_t_batched(wv, xs, F, N, split_out=True)
         assert npad2 % 8 == 0 and vts.shape == (F, C, 2 * npad2)
         h, l = decode_split(vts.reshape(F * C, 2 * npad2))
-        assert torch.equal(h[:, :N], vt.reshape(F * C, npad)[:, :N].to(torch.bfloat16).float())
+        vref = vt.reshape(F * C, npad)[:, :N]         # (the two launches are tuned separately: same values up to the fp32 summation order)
+        assert ((h + l)[:, :N] - vref).abs().max().item() < 2e-5 * vref.abs().max().item()
         for so in (False, True):
             pre = ops.attention(qks[:, :2 * C], [(qks[:, 2 * C:], vts.reshape(-1, 2 * npad2), N, 1, C * 2 * npad2)], B=F, H=H, Nq=N,
                                 scale=0.125, x3=True, qkv_split=True, split_out=so)
             if so:
                 check_split(f"attention qkv_split F{F} N{N}", pre, raw)
             else:
-                assert torch.equal(pre, raw), f"F{F} N{N}: {((pre - raw).norm() / raw.norm()).item():.3e}"
+                # (q | k / V^T of the two paths come from separately tuned launches: same values up to the fp32 summation order)
+                assert ((pre - raw).norm() / raw.norm()).item() < 1e-5, f"F{F} N{N}: {((pre - raw).norm() / raw.norm()).item():.3e}"
         for variant in (4, 5):      # flash_attn2_kernel (skewed query blocks; one / two waves per SIMD): same sums in the same order per accumulator
             pre = ops.attention(qks[:, :2 * C], [(qks[:, 2 * C:], vts.reshape(-1, 2 * npad2), N, 1, C * 2 * npad2)], B=F, H=H, Nq=N,
                                 scale=0.125, x3=True, qkv_split=True, variant=variant)

@@ -65,6 +65,18 @@ case $JOB in
     grep -E "passed|failed|rc=|Error|error|variant" $O/pytest.log | tail -12
     timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-1500 $O/bench.json
     ;;
+  r4f)         # paired 128-byte epilogue stores (second / third generation): bit-identical? fixed cost per launch? census + bench
+    ( time timeout 900 python -m pytest tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_bf16x3_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error" $O/pytest.log | tail -6
+    timeout 300 python tools/gemm_kscan.py > $O/kscan.log 2>&1; show $O/kscan.log 230
+    timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
+    ;;
+  r4g)         # the table re-measured with the round-4 epilogue (fixed cost per tile 30 -> ~5 us on the phased tiles), then the bench line on it
+    TAG=$TAG bash $0 retune bf16x3 bf16
+    cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    grep -c "" $O/gfx950.json.log; awk '{print $3}' $O/gfx950.json.log | sort | uniq -c | sort -rn | head -12
+    timeout 500 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
+    ;;
   tests)       # gpu test files given as arguments (default: all)
     ( time timeout 1200 python -m pytest ${@:-tests} -m gpu -q -x --durations=8 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
     grep -E "passed|failed|rc=|Error" $O/pytest.log | tail -8
