@@ -53,7 +53,7 @@ template <typename T> __device__ __forceinline__ int swz_key(int row) {
 // is ONE 16-byte load per block outside the row loop, the residual one 16-byte load issued a row block AHEAD of the stores (counted
 // wait), and the pre-split output is written as whole 16-byte hi / lo chunks (the two lanes of an 8-column group trade their halves
 // with v_permlane16_swap) instead of two 8-byte pieces per lane. Same values, same addresses.
-template <int MB, int NB, bool OSPLIT, bool VECONLY = false>   // VECONLY: the host checked the vector-store conditions (no scalar fallback code)
+template <int MB, int NB, bool OSPLIT, bool VECONLY = false, bool ROWS4 = false>   // VECONLY: the host checked the vector-store conditions (no scalar fallback code); ROWS4: 4-byte element kernels (bf16x3) - the 16-bit-row fast paths are not instantiated
 __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f32x4 (&acc)[MB][NB], const int m_w0, const int n_w0,
                                              const long e_bz, const int e_kz, const bool partial, const int lr, const int lq) {
     const int odt = partial ? GEO4D_F32 : p.out_dtype;
@@ -150,6 +150,74 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
                         e[j] = (acc[a][b][j] * p.alpha + __uint_as_float(bv[j])) * gelu_erf_f(acc[a][b + 2 < NB ? b + 2 : b][j] * p.alpha + __uint_as_float(bg[j]));
                     const u32x4 c = chunk_of(e);
                     __builtin_amdgcn_raw_buffer_store_b128(c, rsO, (ok ? offO + a * rowO : OOB) + (unsigned)(32 * (b >> 2) + 16 * (b & 1)) * 4u, 0, 0);
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (!ROWS4)
+    if (vec_ok && odt != GEO4D_F32 && !geglu && p.act == 0 && !p.rowbias && !(p.bias && p.bias_per_row)) {
+        // 16-bit rows (the bf16 / f16 modes): the same structure with 8-byte vectors
+        const bool isbf = odt == GEO4D_BF16;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((unsigned short*)O + obase + (long)m_w0 * ldo + n_w0), 0, OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(has_res ? (const void*)((const unsigned short*)p.R + rbase + (long)m_w0 * p.ldr + n_w0) : p.zeros), 0, has_res ? OOB : 0u, 0x00020000);
+        const int nleft = p.N - n_w0;
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(p.bias ? (const void*)(p.bias + n_w0) : p.zeros), 0, (p.bias && nleft > 0) ? (unsigned)nleft * 4u : 0u, 0x00020000);
+        const unsigned offO = (unsigned)(lr * (int)ldo + 4 * lq) * 2u, offR = (unsigned)(lr * (int)p.ldr + 4 * lq) * 2u;
+        const unsigned rowO = (unsigned)ldo * 32u, rowR = (unsigned)p.ldr * 32u;       // bytes per 16-row block
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const bool colok = n_w0 + 16 * b + 4 * lq < p.N;
+            const u32x4 bcu = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b, 0, 0);
+            u32x2 ru = __builtin_amdgcn_raw_buffer_load_b64(rsR, ((colok && m_w0 + lr < p.M) ? offR : OOB) + 32u * b, 0, 0);
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const bool ok = colok && m_w0 + a * 16 + lr < p.M;
+                float rf[4];
+                if (isbf) {
+                    rf[0] = __uint_as_float(ru[0] << 16); rf[1] = __uint_as_float(ru[0] & 0xffff0000u);
+                    rf[2] = __uint_as_float(ru[1] << 16); rf[3] = __uint_as_float(ru[1] & 0xffff0000u);
+                } else {
+                    rf[0] = f16_bits_to_f32((unsigned short)(ru[0] & 0xffffu)); rf[1] = f16_bits_to_f32((unsigned short)(ru[0] >> 16));
+                    rf[2] = f16_bits_to_f32((unsigned short)(ru[1] & 0xffffu)); rf[3] = f16_bits_to_f32((unsigned short)(ru[1] >> 16));
+                }
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = (acc[a][b][j] * p.alpha + __uint_as_float(bcu[j])) + rf[j];
+                const u32x2 c = isbf ? u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])} : u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
+                if (a + 1 < MB)
+                    ru = __builtin_amdgcn_raw_buffer_load_b64(rsR, ((colok && m_w0 + (a + 1) * 16 + lr < p.M) ? offR : OOB) + 32u * b, (a + 1) * rowR, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(c, rsO, (ok ? offO + a * rowO : OOB) + 32u * b, 0, 0);
+            }
+        }
+        return;
+    }
+    if constexpr (!ROWS4)
+    if (vec_ok && odt != GEO4D_F32 && geglu) {
+        if constexpr (NB % 4 == 0) {
+            const bool isbf = odt == GEO4D_BF16;
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((unsigned short*)O + obase + (long)m_w0 * ldo + (n_w0 >> 1)), 0, OOB, 0x00020000);
+            const int nleft = p.N - n_w0;
+            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_ptr(p.bias ? (const void*)(p.bias + n_w0) : p.zeros), 0, (p.bias && nleft > 0) ? (unsigned)nleft * 4u : 0u, 0x00020000);
+            const unsigned offO = (unsigned)(lr * (int)ldo + 4 * lq) * 2u, rowO = (unsigned)ldo * 32u;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if ((b & 3) >= 2) continue;
+                const bool grp = n_w0 + 16 * (b & ~3) + 64 <= p.N;
+                const u32x4 bv = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b, 0, 0);
+                const u32x4 bg = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b + 128u, 0, 0);
+#pragma unroll
+                for (int a = 0; a < MB; ++a) {
+                    const bool ok = grp && m_w0 + a * 16 + lr < p.M;
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        e[j] = (acc[a][b][j] * p.alpha + __uint_as_float(bv[j])) * gelu_erf_f(acc[a][b + 2 < NB ? b + 2 : b][j] * p.alpha + __uint_as_float(bg[j]));
+                    const u32x2 c = isbf ? u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])} : u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(c, rsO, (ok ? offO + a * rowO : OOB) + (unsigned)(32 * (b >> 2) + 16 * (b & 1)) * 2u, 0, 0);
                 }
             }
         }
@@ -432,7 +500,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
 
     const bool partial = splits > 1;                  // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
     auto epilogue = [&](int e_tm, int e_tn, long e_bz, int e_kz) {
-        reg_epilogue<MB, NB, OSPLIT>(p, acc, e_tm * BM + wr * WTM, e_tn * BN + wc * WTN, e_bz, e_kz, partial, lr, lq);
+        reg_epilogue<MB, NB, OSPLIT, false, IsX3<T>::value>(p, acc, e_tm * BM + wr * WTM, e_tn * BN + wc * WTN, e_bz, e_kz, partial, lr, lq);
     };
 
     // ---- persistent tile loop --------------------------------------------------------------------------------------------------------

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             // (dozens of 64-bit row offsets) are hoisted out of the tile loop and live - spilled - across the K loop
             int lr_ = lr, lq_ = lq;
             asm volatile("" : "+v"(lr_), "+v"(lq_));
-            reg_epilogue<MB, NB, OSPLIT, true>(p, acc, tmC * BM + wr * WTM, tnC * BN + wc * WTN, bzC, kzC, partial, lr_, lq_);
+            reg_epilogue<MB, NB, OSPLIT, true, IsX3<T>::value>(p, acc, tmC * BM + wr * WTM, tnC * BN + wc * WTN, bzC, kzC, partial, lr_, lq_);
         }
         // a REAL s_waitcnt vmcnt(0) (the builtin, which the compiler's wait-count pass tracks; an inline-asm one it does not see):
         // without it the pass has to assume pending loads into VGPRs at the K loop's header and drains the DMA queue every slab

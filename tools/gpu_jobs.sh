@@ -77,6 +77,13 @@ case $JOB in
     grep -c "" $O/gfx950.json.log; awk '{print $3}' $O/gfx950.json.log | sort | uniq -c | sort -rn | head -12
     timeout 500 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
     ;;
+  r4h)         # 16-bit-row fast paths: the GEMM tests of every generation / dtype, bf16 table re-measured, bench line
+    ( time timeout 900 python -m pytest tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_bf16x3_gpu.py tests/test_kernels_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error" $O/pytest.log | tail -6
+    TAG=$TAG bash $0 retune bf16
+    cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    timeout 500 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
+    ;;
   tests)       # gpu test files given as arguments (default: all)
     ( time timeout 1200 python -m pytest ${@:-tests} -m gpu -q -x --durations=8 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
     grep -E "passed|failed|rc=|Error" $O/pytest.log | tail -8
