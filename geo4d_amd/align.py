@@ -607,6 +607,7 @@ class GroupAligner:
                     first.setdefault(i, (g, k))
             rm = raymaps.reshape(G, S, H, W, 3)
             per_image = estimate_focal_weiszfeld(torch.stack([rm[g, k] for g, k in (first[i] for i in range(self.n))]).to(self.dev))
+            per_image = torch.where(torch.isfinite(per_image) & (per_image > 0), per_image, torch.full_like(per_image, max(H, W) / (2.0 * math.tan(math.radians(30.0)))))
             self.init_focals = per_image
             focal = float(per_image.mean()) if self.shared_focal else per_image
         if focal is None:
@@ -617,9 +618,15 @@ class GroupAligner:
             fy = (v * p0[:, 2] / p0[:, 1])[ok & (v.abs() > H / 8)]
             cand = torch.cat([fx[torch.isfinite(fx)], fy[torch.isfinite(fy)]])
             focal = float(cand.median()) if cand.numel() else float(max(H, W))
+        # degenerate predictions (e.g. the synthetic noise maps of bench.py's clip mode) can yield a non-positive / non-finite estimate, whose
+        # log the reference would carry into the optimisation as NaN: fall back to the 60-degree field of view dust3r's estimator is scaled by
+        fbase = max(H, W) / (2.0 * math.tan(math.radians(30.0)))
         if torch.is_tensor(focal):
+            focal = torch.where(torch.isfinite(focal) & (focal > 0), focal, torch.full_like(focal, fbase))
             self.P["im_focals"][:, 0] = FOCAL_BREAK * torch.log(focal)
         else:
+            if not (math.isfinite(focal) and focal > 0):
+                focal = fbase
             self.P["im_focals"][:] = FOCAL_BREAK * math.log(focal)
         sky = 0.0
         for i in range(self.n):

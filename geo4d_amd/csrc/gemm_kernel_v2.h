@@ -94,31 +94,54 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (void*)(((unsigned long long)hi << 32) | lo);
     };
-    if (wide && !geglu && (partial || (p.act == 0 && !p.rowbias && !(p.bias && p.bias_per_row)))) {
+    if (wide && !geglu && (partial || p.act == 0)) {
         const float alpha = partial ? 1.0f : p.alpha;
-        const bool hb = !partial && p.bias != nullptr;
+        const bool hb = !partial && p.bias != nullptr && !p.bias_per_row;      // bias per output column
+        const bool hr = !partial && p.bias != nullptr && p.bias_per_row;       // bias per output row (the operand-swapped V^T projection)
+        const bool ht = !partial && p.rowbias != nullptr;                      // row-bias table (the ResBlocks' per-frame emb add): row m / rowbias_div
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((float*)O + obase + (long)m_w0 * ldo + n_w0), 0, OOB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
             uniform_ptr(has_res ? (const void*)((const float*)p.R + rbase + (long)m_w0 * p.ldr + n_w0) : p.zeros), 0, has_res ? OOB : 0u, 0x00020000);
-        const int nleft = p.N - n_w0;
+        const int nleft = p.N - n_w0, mleft = p.M - m_w0;
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
             uniform_ptr(hb ? (const void*)(p.bias + n_w0) : p.zeros), 0, (hb && nleft > 0) ? (unsigned)nleft * 4u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsBr = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(hr ? (const void*)(p.bias + m_w0) : p.zeros), 0, (hr && mleft > 0) ? (unsigned)mleft * 4u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ht ? (const void*)(p.rowbias + n_w0) : p.zeros), 0, ht ? OOB : 0u, 0x00020000);
         const unsigned offO = (unsigned)(lr * (int)ldo + 4 * lq) * 4u, offR = (unsigned)(lr * (int)p.ldr + 4 * lq) * 4u;
         const unsigned rowO = (unsigned)ldo * 64u, rowR = (unsigned)p.ldr * 64u;       // bytes per 16-row block
+        unsigned offT[MB];                                                              // byte offset of this lane's row-bias row per row block
+#pragma unroll
+        for (int a = 0; a < MB; ++a) offT[a] = 0u;
+        if (ht) {
+            const unsigned ldt = (unsigned)(p.ldrb ? p.ldrb : (long)p.N);
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const int m = m_w0 + a * 16 + lr;
+                offT[a] = ((unsigned)((m < p.M ? m : p.M - 1) / p.rowbias_div) * ldt + 4u * lq) * 4u;
+            }
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const bool colok = n_w0 + 16 * b + 4 * lq < p.N;
             const u32x4 bcu = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b, 0, 0);
             u32x4 ru = __builtin_amdgcn_raw_buffer_load_b128(rsR, ((colok && m_w0 + lr < p.M) ? offR : OOB) + 64u * b, 0, 0);
+            u32x4 tu = __builtin_amdgcn_raw_buffer_load_b128(rsT, (colok ? offT[0] : OOB) + 64u * b, 0, 0);
+            unsigned bru = __builtin_amdgcn_raw_buffer_load_b32(rsBr, (unsigned)lr * 4u, 0, 0);
 #pragma unroll
             for (int a = 0; a < MB; ++a) {
                 const bool ok = colok && m_w0 + a * 16 + lr < p.M;
+                const float brow = __uint_as_float(bru);
                 float e[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = (acc[a][b][j] * alpha + __uint_as_float(bcu[j])) + __uint_as_float(ru[j]);
+                for (int j = 0; j < 4; ++j)
+                    e[j] = (((acc[a][b][j] * alpha + brow) + __uint_as_float(bcu[j])) + __uint_as_float(tu[j])) + __uint_as_float(ru[j]);
                 const u32x4 c = chunk_of(e);
-                if (a + 1 < MB)              // the next row block's residual goes out BEFORE this block's store: its wait stays counted
+                if (a + 1 < MB) {            // the next row block's residual / row biases go out BEFORE this block's store: their wait stays counted
                     ru = __builtin_amdgcn_raw_buffer_load_b128(rsR, ((colok && m_w0 + (a + 1) * 16 + lr < p.M) ? offR : OOB) + 64u * b, (a + 1) * rowR, 0);
+                    tu = __builtin_amdgcn_raw_buffer_load_b128(rsT, (colok ? offT[a + 1 < MB ? a + 1 : a] : OOB) + 64u * b, 0, 0);
+                    bru = __builtin_amdgcn_raw_buffer_load_b32(rsBr, (unsigned)(lr + 16 * (a + 1)) * 4u, 0, 0);
+                }
                 // (row-block offset in the VGPR offset, soffset = 0: with an SGPR soffset hipcc's hazard recognizer assumes a 16-byte buffer
                 // store's data registers may be overwritten right away - on gfx950 the last lanes of every 16 then stored the NEXT block's
                 // values, tools/dbg_epilogue.py; measured round 4)

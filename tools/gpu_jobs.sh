@@ -84,6 +84,20 @@ case $JOB in
     cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
     timeout 500 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
     ;;
+  r4i)         # per-row bias in the fast epilogue (V^T projections): tests, bench; the configs[2] clip line (64 frames -> 14 windows + alignment) on one GPU
+    ( time timeout 900 python -m pytest tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_bf16x3_gpu.py tests/test_kernels_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error" $O/pytest.log | tail -6
+    timeout 500 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
+    timeout 600 python bench.py --clip-frames 64 --no-cpu-baseline > $O/clip64.json 2> $O/clip64.err; tail -2 $O/clip64.err; cut -c1-2000 $O/clip64.json
+    ;;
+  r4j)         # row-bias table + per-row bias in the fast epilogue: tests, table re-measured (both modes), bench, the 64-frame clip line
+    ( time timeout 900 python -m pytest tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_bf16x3_gpu.py tests/test_kernels_gpu.py tests/test_parity_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error" $O/pytest.log | tail -6
+    TAG=$TAG bash $0 retune bf16x3 bf16
+    cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    timeout 500 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
+    timeout 600 python bench.py --clip-frames 64 --no-cpu-baseline > $O/clip64.json 2> $O/clip64.err; tail -2 $O/clip64.err; cut -c1-2400 $O/clip64.json
+    ;;
   tests)       # gpu test files given as arguments (default: all)
     ( time timeout 1200 python -m pytest ${@:-tests} -m gpu -q -x --durations=8 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
     grep -E "passed|failed|rc=|Error" $O/pytest.log | tail -8
