@@ -21,4 +21,5 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; d
 done
 python $R/tools/pmc_summary.py $O/pmc.md $O/pmc.json $(find /tmp/prof/pmc1 /tmp/prof/pmc2 /tmp/prof/pmc3 -name "*counter_collection.csv") > $O/pmc_summary.log 2>&1
 grep -E "passed|failed|rc=" $O/pytest.log | tail -3; tail -3 $O/smoke.log; cut -c1-300 $O/bench.json; tail -3 $O/pmc_summary.log
-timeout 300 python $R/tools/gemm_bench.py --dtype bf16x3 --iters 10 > $O/gemm_x3.log 2>&1; tail -2 $O/gemm_x3.log
+timeout 300 python $R/tools/gemm_bench.py --dtype bf16x3 --presplit --iters 10 --vendor > $O/gemm_x3.log 2>&1; tail -2 $O/gemm_x3.log
+timeout 200 python $R/tools/attn_bench.py bf16 bf16x3 > $O/attn.log 2>&1; grep "2560\|forward" $O/attn.log | grep "v4\|v3 \|v1 " | tail -8
