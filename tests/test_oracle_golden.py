@@ -245,7 +245,7 @@ def test_alignment_oracle_vs_reference_optimizer():
     P = {k: v.clone().requires_grad_(True) for k, v in g["init"].items()}
     loss = oalign.alignment_loss(P, data, **kw)
     loss.backward()
-    assert abs(float(loss) - g["loss0"]) < 1e-5 * abs(g["loss0"]), (float(loss), g["loss0"])
+    assert abs(float(loss.detach()) - g["loss0"]) < 1e-5 * abs(g["loss0"]), (float(loss.detach()), g["loss0"])
     for k in P:
         assert rel(P[k].grad, g["grads"][k]) < 1e-4, (k, rel(P[k].grad, g["grads"][k]))
     P = {k: v.clone().requires_grad_(True) for k, v in g["init"].items()}
