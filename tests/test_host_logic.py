@@ -329,3 +329,23 @@ def test_split_act_is_rejected_outside_gemm_operands():
     with pytest.raises(AssertionError, match="no column-offset views"):
         ops._split_out_ok(torch.zeros((4, 64), dtype=torch.bfloat16)[:, 16:48].as_subclass(ops.SplitAct), 4)
     ops._split_out_ok(ops.SplitAct.wrap(torch.zeros((4, 32), dtype=torch.bfloat16)), 4)
+
+
+def test_bench_clip_mode_synthetic_scene_is_a_valid_alignment_input():
+    """bench.py --clip-frames runs its alignment phases on `synthetic_scene_maps` (random-init weights decode to noise): the maps must
+    survive the post-decode math of the reference script (no sky / far-away masks, positive depth, inverse depth inside its range) and
+    carry the focal they were built with."""
+    import bench
+    from geo4d_amd.align import estimate_focal_weiszfeld
+    from geo4d_amd.pipeline import postprocess_window, window_slices
+    H, W = 40, 64
+    sl = window_slices(24, 4, 16)
+    maps, traj = bench.synthetic_scene_maps(sl, 16, H, W, torch.device("cpu"))
+    assert maps.shape == (len(sl), 11, 16, H, W) and traj.shape == (len(sl), 16, 4, 4) and torch.isfinite(maps).all()
+    for g in range(len(sl)):
+        p = postprocess_window(maps[g][None])
+        assert p["valid"].all() and (p["pts3d"][..., 2] > 0.3).all() and (p["conf"] > 0).all()
+        assert (p["inverse_depthmap"] > 0.4).all() and (p["inverse_depthmap"] < 0.8).all()
+        f = estimate_focal_weiszfeld(p["raymap"][:2])
+        assert torch.allclose(f, torch.full_like(f, 1.2 * W), rtol=1e-4)
+    assert torch.allclose(traj[1, 3, :3, 3], torch.tensor([0.03, 0.0, 0.0]))      # the camera slides 0.01 per frame inside a window
