@@ -385,7 +385,11 @@ __global__ __launch_bounds__(256, OCC) void flash_attn2_kernel(const geo4d_atten
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware mapping: consecutive hardware workgroup ids go to different XCDs (8 private L2s); remapped so that the query blocks
+    // of one (frame, head) - which all stream the same K / V^T - are neighbours on ONE XCD
+    const long nwg = (long)gridDim.x * gridDim.y * gridDim.z;
+    const long lid = xcd_remap(blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z), nwg);
+    const int bx = (int)(lid % gridDim.x), h = (int)((lid / gridDim.x) % gridDim.y), b = (int)(lid / ((long)gridDim.x * gridDim.y));
     const T* __restrict__ Z = (const T*)p.zeros;
     const int nk = p.Nk[0];
     const int ntile = (nk + 63) >> 6;
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256, OCC) void flash_attn2_kernel(const geo4d_atten
     u32x4 qf[2][4], ql[2][X3 ? 4 : 1];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        qrow[qb] = blockIdx.x * 256 + wave * 64 + qb * 32 + li;
+        qrow[qb] = bx * 256 + wave * 64 + qb * 32 + li;
         qok[qb] = qrow[qb] < p.Nq;
         const T* qp = (const T*)p.q + ((long)b * p.Nq + (qok[qb] ? qrow[qb] : 0)) * p.ldq + h * 64;
 #pragma unroll
@@ -810,9 +814,12 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     // 4 / 5 = flash_attn2_kernel (round 4: skewed query blocks, matrix work beside every softmax): one key/value set, 16-bit types
     // (4) and bf16x3 on pre-split inputs (4 = one wave per SIMD with the whole register file, 5 = two waves per SIMD).
     // Default since round 4 wherever it applies and a 256-row workgroup is not mostly empty (measured, profiles/r04_attention.md:
-    // bf16 N = 2560 199.9 -> 194.7 us, N = 640 33.6 -> 32.8; pre-split bf16x3 N = 2560 524 -> 474 us, N = 640 76.3 -> 70.7)
+    // bf16 N = 2560 199.9 -> 189.9 us, N = 640 33.6 -> 31.4; pre-split bf16x3 N = 2560 524 -> 443 us, N = 640 76.3 -> 67.8)
+    // (bf16x3: the two-waves-per-SIMD build wins on the long level-0 sequences once the workgroups of a (frame, head) share an XCD:
+    // N = 2560 467 us (variant 4) vs 443 us (variant 5); N = 640 67.8 vs 70.3 us)
     if (variant == 0 && p.nseg == 1 && p.Nq >= 256 &&
-        (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16 || (p.dtype == GEO4D_BF16X3 && p.qkv_split))) variant = 4;
+        (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16 || (p.dtype == GEO4D_BF16X3 && p.qkv_split)))
+        variant = (p.dtype == GEO4D_BF16X3 && p.Nq >= 1024) ? 5 : 4;
     if (variant >= 4) {
         const bool ok16 = (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16) && variant == 4;
         const bool okx3 = p.dtype == GEO4D_BF16X3 && p.qkv_split;
