@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the bench line: the round-3 tree (exported to gpurun_ab_r3/ by `git archive d7ec541`, built ON the GPU box) against this
-# tree, interleaved A B A B so that clock drift between the runs shows. usage (via gpurun): bash tools/ab_same_box.sh
+# tree, interleaved A B A B so that clock drift between the runs shows. Prepare (build container): mkdir gpurun_ab_r3 && git archive d7ec541 | tar -x -C gpurun_ab_r3
+# (git-ignored; drop its tests/golden and profiles to keep the push small). usage (via gpurun): bash tools/ab_same_box.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4_ab; mkdir -p $O
 cd $R/gpurun_ab_r3 && ( time make -j64 > $O/build_r3.log 2>&1 ) 2>&1 | grep real
