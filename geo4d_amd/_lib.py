@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GEO4D_HIP_LIB: load another build of the SAME library (A/B builds of a kernel: tools/gpu_r2k.sh); the ABI handshake below still applies
 LIB_PATH = os.environ.get("GEO4D_HIP_LIB") or os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 
@@ -47,7 +47,7 @@ class GroupNorm(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("ldx", C.c_long), ("ldy", C.c_long),
         ("F", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("frames_per_stat", C.c_int),
-        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("split_out", C.c_int),
+        ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("split_out", C.c_int), ("colsum_rows", C.c_int),
     ]
 
 
@@ -95,6 +95,7 @@ class AlignSmall(C.Structure):
 # name -> (restype, argtypes); checked against include/geo4d_hip.h by tests/test_host_logic.py::test_c_abi_exports_every_declared_symbol
 SIGNATURES = {
     "geo4d_conv_gemm": (C.c_int, [C.POINTER(ConvGemm), C.c_void_p]),
+    "geo4d_conv_gemm_colsum_rows": (C.c_int, [C.POINTER(ConvGemm)]),
     "geo4d_groupnorm_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "geo4d_groupnorm": (C.c_int, [C.POINTER(GroupNorm), C.c_void_p]),
     "geo4d_layernorm": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_void_p,

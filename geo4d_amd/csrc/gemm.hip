@@ -43,6 +43,11 @@ extern template int launch_typed<bf16_t>(const geo4d_conv_gemm_t&, hipStream_t);
 extern template int launch_typed<f16_t>(const geo4d_conv_gemm_t&, hipStream_t);
 extern template int launch_typed<bf16x3_t>(const geo4d_conv_gemm_t&, hipStream_t);
 }  // namespace geo4d_gemm
+namespace geo4d_gemm {
+template <typename T> int colsum_rows_v23(const geo4d_conv_gemm_t& p);      // gemm_kernel_v3.h, instantiated in gemm_v3_bf16x3.hip / gemm_v3_bf16.hip
+extern template int colsum_rows_v23<bf16x3_t>(const geo4d_conv_gemm_t&);
+extern template int colsum_rows_v23<bf16_t>(const geo4d_conv_gemm_t&);
+}  // namespace geo4d_gemm
 using geo4d_gemm::BKC;
 using geo4d_gemm::MAXTAP;
 using geo4d_gemm::launch_typed;
@@ -83,7 +88,7 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
             return GEO4D_EINVAL;
         }
     }
-    if (p.gn_colsum) {
+    if (p.gn_colsum && p.tile_hint < 21) {      // (first generation: one entry per 32 rows; the second / third generation launchers check their own form)
         const int oesz = p.out_dtype == GEO4D_F32 ? 4 : 2;
         if ((p.M % 32) || (p.N % 8) || p.out_nchw || p.act == 2 || p.batch != 1 || p.split_k != 1 || ((p.ldo * oesz) % 16) || ((uintptr_t)p.O % 16) ||
             ((uintptr_t)p.gn_colsum % 16) || (p.R && (((p.ldr * oesz) % 16) || ((uintptr_t)p.R % 16)))) {
@@ -102,4 +107,21 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
         case GEO4D_BF16X3: return launch_typed<bf16x3_t>(p, s);
         default: return launch_typed<f16_t>(p, s);
     }
+}
+
+// Rows of the output that ONE gn_colsum entry of the launch `*pp` describes covers (tile_hint / split_k as they will be launched;
+// the gn_colsum field itself is ignored): 32 for the first-generation tiles, the wave tile's rows for the second / third generation,
+// 0 = this launch cannot emit the sums (the caller then leaves gn_colsum null and the GroupNorm runs its own statistics pass).
+extern "C" int geo4d_conv_gemm_colsum_rows(const geo4d_conv_gemm_t* pp) {
+    if (!pp) return 0;
+    const geo4d_conv_gemm_t& p = *pp;
+    if (p.tile_hint < 21) {
+        const int oesz = p.out_dtype == GEO4D_F32 ? 4 : 2;
+        const bool ok = !(p.M % 32) && !(p.N % 8) && !p.out_nchw && p.act != 2 && p.batch == 1 && p.split_k <= 1 && !p.o_split && !((p.ldo * oesz) % 16) &&
+                        !((uintptr_t)p.O % 16) && (!p.R || (!((p.ldr * oesz) % 16) && !((uintptr_t)p.R % 16)));
+        return ok ? 32 : 0;
+    }
+    if (p.dtype == GEO4D_BF16X3) return geo4d_gemm::colsum_rows_v23<bf16x3_t>(p);
+    if (p.dtype == GEO4D_BF16) return geo4d_gemm::colsum_rows_v23<bf16_t>(p);
+    return 0;
 }

@@ -12,7 +12,7 @@
 //   3. persistent workgroups: grid = resident workgroups, a static round-robin tile loop; the NEXT tile's gather table, weight-row
 //      pointers and first K slab (LDS-DMA) are issued BEFORE the current tile's epilogue, so the DMA latency and the table's
 //      integer divides run under the epilogue's global traffic instead of in front of the next tile's first MFMA.
-// Not covered here (the host keeps such launches on conv_gemm_kernel): f32 element type, NCTHW outputs, gn_colsum.
+// Not covered here (the host keeps such launches on conv_gemm_kernel): f32 element type, NCTHW outputs.
 #pragma once
 #include "gemm_kernel.h"
 
@@ -53,6 +53,22 @@ template <typename T> __device__ __forceinline__ int swz_key(int row) {
 // is ONE 16-byte load per block outside the row loop, the residual one 16-byte load issued a row block AHEAD of the stores (counted
 // wait), and the pre-split output is written as whole 16-byte hi / lo chunks (the two lanes of an 8-column group trade their halves
 // with v_permlane16_swap) instead of two 8-byte pieces per lane. Same values, same addresses.
+// gn_colsum from the fast path (round 4): per WAVE-TILE row range (MB x 16 rows) and output column, (sum, sum of squares) of the values
+// this launch stores - the consumer GroupNorm's statistics pass, skipped (norm.hip gn_finalize_cols, rows per entry = the wave tile's
+// rows). Available where the plain f32-row fast path runs (no activation, no split-K, no pre-split output) and M is a multiple of the
+// wave tile's rows; geo4d_conv_gemm_colsum_rows() tells the host which rows a launch will use (0 = not available).
+inline bool colsum_fast_ok(const geo4d_conv_gemm_t& p, int sp) {
+    return sp == 1 && p.act == 0 && !p.o_split && !p.out_nchw && p.batch == 1 && p.out_dtype == GEO4D_F32 && (p.N & 3) == 0 && (p.ldo & 3) == 0 &&
+           ((uintptr_t)p.O % 16) == 0 && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R % 16) == 0));
+}
+inline int v2_wave_rows(int hint) { return hint == 22 ? 64 : hint == 23 ? 80 : hint == 25 ? 64 : (hint == 27 || hint == 28) ? 32 : 0; }
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes lr of a 16-lane row, fixed order (DPP: xor 1, xor 2, half mirror, mirror)
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));     // row_mirror
+    return v;
+}
 template <int MB, int NB, bool OSPLIT, bool VECONLY = false, bool ROWS4 = false>   // VECONLY: the host checked the vector-store conditions (no scalar fallback code); ROWS4: 4-byte element kernels (bf16x3) - the 16-bit-row fast paths are not instantiated
 __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f32x4 (&acc)[MB][NB], const int m_w0, const int n_w0,
                                              const long e_bz, const int e_kz, const bool partial, const int lr, const int lq) {
@@ -110,6 +126,11 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
         const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ht ? (const void*)(p.rowbias + n_w0) : p.zeros), 0, ht ? OOB : 0u, 0x00020000);
         const unsigned offO = (unsigned)(lr * (int)ldo + 4 * lq) * 4u, offR = (unsigned)(lr * (int)p.ldr + 4 * lq) * 4u;
         const unsigned rowO = (unsigned)ldo * 64u, rowR = (unsigned)p.ldr * 64u;       // bytes per 16-row block
+        // (the launcher checked M % (16 MB) == 0 and the fast-path conditions; a wave tile that starts beyond M - the last row tile of a
+        // ragged M - has no entry: its chunk index would lie beyond the [M / rows] buffer)
+        const bool gn = !partial && p.gn_colsum != nullptr && m_w0 < p.M;
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(gn ? (const void*)(p.gn_colsum + ((long)(m_w0 / (16 * MB)) * p.N + n_w0) * 2) : p.zeros), 0, gn ? OOB : 0u, 0x00020000);
         unsigned offT[MB];                                                              // byte offset of this lane's row-bias row per row block
 #pragma unroll
         for (int a = 0; a < MB; ++a) offT[a] = 0u;
@@ -128,6 +149,7 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
             u32x4 ru = __builtin_amdgcn_raw_buffer_load_b128(rsR, ((colok && m_w0 + lr < p.M) ? offR : OOB) + 64u * b, 0, 0);
             u32x4 tu = __builtin_amdgcn_raw_buffer_load_b128(rsT, (colok ? offT[0] : OOB) + 64u * b, 0, 0);
             unsigned bru = __builtin_amdgcn_raw_buffer_load_b32(rsBr, (unsigned)lr * 4u, 0, 0);
+            float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < MB; ++a) {
                 const bool ok = colok && m_w0 + a * 16 + lr < p.M;
@@ -136,6 +158,10 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     e[j] = (((acc[a][b][j] * alpha + brow) + __uint_as_float(bcu[j])) + __uint_as_float(tu[j])) + __uint_as_float(ru[j]);
+                if (gn) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { cs[j] += e[j]; cq[j] += e[j] * e[j]; }
+                }
                 const u32x4 c = chunk_of(e);
                 if (a + 1 < MB) {            // the next row block's residual / row biases go out BEFORE this block's store: their wait stays counted
                     ru = __builtin_amdgcn_raw_buffer_load_b128(rsR, ((colok && m_w0 + (a + 1) * 16 + lr < p.M) ? offR : OOB) + 64u * b, (a + 1) * rowR, 0);
@@ -146,6 +172,13 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
                 // store's data registers may be overwritten right away - on gfx950 the last lanes of every 16 then stored the NEXT block's
                 // values, tools/dbg_epilogue.py; measured round 4)
                 __builtin_amdgcn_raw_buffer_store_b128(c, rsO, (ok ? offO + a * rowO : OOB) + 64u * b, 0, 0);
+            }
+            if (gn) {                        // [chunk][n][2]: lane lr == 0 of every 16-lane row writes its 4 columns' (sum, sum of squares)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cs[j] = row16_sum(cs[j]); cq[j] = row16_sum(cq[j]); }
+                const unsigned offC = (lr == 0 && colok) ? (unsigned)(16 * b + 4 * lq) * 8u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(cs[0]), __float_as_uint(cq[0]), __float_as_uint(cs[1]), __float_as_uint(cq[1])}, rsC, offC, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(cs[2]), __float_as_uint(cq[2]), __float_as_uint(cs[3]), __float_as_uint(cq[3])}, rsC, offC + 16u, 0, 0);
             }
         }
         return;
@@ -635,8 +668,8 @@ int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
         geo4d_set_error("conv_gemm: tile hints 22..28 serve bf16 / bf16x3 (the exact-f32 and the f16 modes stay on hints 0..17)");
         return GEO4D_EINVAL;
     } else {
-        if (p.out_nchw || p.gn_colsum) {
-            geo4d_set_error("conv_gemm: tile hints 22..28 have no NCTHW / gn_colsum epilogue");
+        if (p.out_nchw) {
+            geo4d_set_error("conv_gemm: tile hints 22..28 have no NCTHW epilogue");
             return GEO4D_EINVAL;
         }
         int sp = 1;
@@ -647,6 +680,10 @@ int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
                 return GEO4D_EINVAL;
             }
             sp = p.split_k;
+        }
+        if (p.gn_colsum && (!colsum_fast_ok(p, sp) || v2_wave_rows(p.tile_hint) == 0 || p.M % v2_wave_rows(p.tile_hint) || ((uintptr_t)p.gn_colsum % 16))) {
+            geo4d_set_error("conv_gemm: gn_colsum on tile hints 22..28 needs the plain f32-row epilogue (no activation / split-K / o_split / batch) and M % wave-tile rows == 0 (geo4d_conv_gemm_colsum_rows)");
+            return GEO4D_EINVAL;
         }
         switch (p.tile_hint) {
             case 22: return launch_v2_cfg<T, 256, 256, 4, 2>(p, sp, stream);

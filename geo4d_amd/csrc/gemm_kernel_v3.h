@@ -500,14 +500,49 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 // (256x256 does not fit: 128 accumulators + the four fragment sets of the prefetching walk spill)
 // Launches the phased stream cannot take (an odd number or fewer than 4 K slabs per tile, an uneven split-K, outputs that are not 4-element aligned,
 // nearest-upsampling gathers, operands beyond the 2 GB buffer window) fall back to the second-generation tile of the same shape.
+inline int v3_wave_rows(int hint) { return hint == 71 ? 96 : hint == 72 ? 80 : hint == 73 ? 128 : 64; }
+inline int v3_fallback_hint(int hint) { return hint == 71 ? 22 : hint == 72 ? 23 : 25; }
+// does the phased stream take this launch (else its second-generation twin does)?
+template <typename T>
+bool v3_native(const geo4d_conv_gemm_t& p, int sp) {
+    const int nslab = p.K / (BKC * Elem<T>::EPC);
+    // the phased kernel carries the vector-store epilogue only (its scalar fallback costs ~900 spilled registers there)
+    const bool geglu = sp == 1 && p.act == 2;
+    const long nout = geglu ? (p.N >> 1) : p.N;
+    const long oesz = (sp > 1 || p.out_dtype == GEO4D_F32) ? 4 : 2;
+    bool vec_ok = (nout & 3) == 0;
+    if (sp > 1) {
+        vec_ok = vec_ok && ((uintptr_t)p.workspace % 16) == 0;
+    } else {
+        vec_ok = vec_ok && (p.ldo & 3) == 0 && ((uintptr_t)p.O % (4 * oesz)) == 0 && (p.batch == 1 || (p.o_bs & 3) == 0);
+        if (p.R) vec_ok = vec_ok && (p.ldr & 3) == 0 && ((uintptr_t)p.R % (4 * oesz)) == 0 && (p.batch == 1 || (p.r_bs & 3) == 0);
+    }
+    // the staging side addresses each operand through a 2 GB buffer window per tile (see the kernel): nearest-upsampling gathers have
+    // no uniform tap offsets, and a tile's rows plus its taps must stay inside the window
+    const long esz = 16 / Elem<T>::EPC;
+    const long frames = 256 / ((long)p.Hout * p.Wout) + 2 + p.KT;
+    const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
+    return !(nslab % sp || ((nslab / sp) & 1) || nslab / sp < 4 || !vec_ok || !window_ok);
+}
+// rows per gn_colsum entry of the launch `p` describes (tile_hint >= 21), 0 = this launch cannot emit the sums
+template <typename T>
+int colsum_rows_v23(const geo4d_conv_gemm_t& p) {
+    const int sp = p.split_k > 1 ? p.split_k : 1;
+    int rows = 0;
+    if (p.tile_hint >= 71 && p.tile_hint <= 74) rows = v3_native<T>(p, sp) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v3_fallback_hint(p.tile_hint));
+    else rows = v2_wave_rows(p.tile_hint);
+    if (rows == 0 || !colsum_fast_ok(p, sp) || p.M % rows) return 0;
+    return rows;
+}
+
 template <typename T>
 int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
     if constexpr (std::is_same<T, float>::value || std::is_same<T, f16_t>::value) {
         geo4d_set_error("conv_gemm: tile hints 71..74 serve bf16 / bf16x3 (the exact-f32 and the f16 modes stay on hints 0..17)");
         return GEO4D_EINVAL;
     } else {
-        if (p.out_nchw || p.gn_colsum) {
-            geo4d_set_error("conv_gemm: tile hints 71..74 have no NCTHW / gn_colsum epilogue");
+        if (p.out_nchw) {
+            geo4d_set_error("conv_gemm: tile hints 71..74 have no NCTHW epilogue");
             return GEO4D_EINVAL;
         }
         int sp = 1;
@@ -523,26 +558,14 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             geo4d_set_error("conv_gemm: unknown tile_hint");
             return GEO4D_EINVAL;
         }
-        // the phased kernel carries the vector-store epilogue only (its scalar fallback costs ~900 spilled registers there)
-        const bool geglu = sp == 1 && p.act == 2;
-        const long nout = geglu ? (p.N >> 1) : p.N;
-        const long oesz = (sp > 1 || p.out_dtype == GEO4D_F32) ? 4 : 2;
-        bool vec_ok = (nout & 3) == 0;
-        if (sp > 1) {
-            vec_ok = vec_ok && ((uintptr_t)p.workspace % 16) == 0;
-        } else {
-            vec_ok = vec_ok && (p.ldo & 3) == 0 && ((uintptr_t)p.O % (4 * oesz)) == 0 && (p.batch == 1 || (p.o_bs & 3) == 0);
-            if (p.R) vec_ok = vec_ok && (p.ldr & 3) == 0 && ((uintptr_t)p.R % (4 * oesz)) == 0 && (p.batch == 1 || (p.r_bs & 3) == 0);
-        }
-        // the staging side addresses each operand through a 2 GB buffer window per tile (see the kernel): nearest-upsampling gathers have
-        // no uniform tap offsets, and a tile's rows plus its taps must stay inside the window
-        const long esz = 16 / Elem<T>::EPC;
-        const long frames = 256 / ((long)p.Hout * p.Wout) + 2 + p.KT;
-        const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
-        if (nslab % sp || ((nslab / sp) & 1) || nslab / sp < 4 || !vec_ok || !window_ok) {
+        if (!v3_native<T>(p, sp)) {
             geo4d_conv_gemm_t q = p;
-            q.tile_hint = p.tile_hint == 71 ? 22 : p.tile_hint == 72 ? 23 : 25;      // (every tile sums in the same order: same bits)
+            q.tile_hint = v3_fallback_hint(p.tile_hint);      // (every tile sums in the same order: same bits)
             return launch_v2_typed<T>(q, stream);
+        }
+        if (p.gn_colsum && (!colsum_fast_ok(p, sp) || p.M % v3_wave_rows(p.tile_hint) || ((uintptr_t)p.gn_colsum % 16))) {
+            geo4d_set_error("conv_gemm: gn_colsum on tile hints 71..74 needs the plain f32-row epilogue (no activation / split-K / o_split / batch) and M % wave-tile rows == 0 (geo4d_conv_gemm_colsum_rows)");
+            return GEO4D_EINVAL;
         }
         switch (p.tile_hint) {
             case 71: return launch_v3_cfg<T, 192, 256, 2, 4>(p, sp, stream);

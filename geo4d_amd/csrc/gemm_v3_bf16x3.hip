@@ -4,4 +4,5 @@
 
 namespace geo4d_gemm {
 template int launch_v3_typed<bf16x3_t>(const geo4d_conv_gemm_t&, hipStream_t);
+template int colsum_rows_v23<bf16x3_t>(const geo4d_conv_gemm_t&);
 }  // namespace geo4d_gemm

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // ---- GroupNorm pass 2': the same merge fed by the column sums the producing conv_gemm's epilogue wrote (gn_colsum): one item
 // per (32-row block, channel of the group) = (n = 32, mean = s / 32, M2 = q - s * mean); replaces pass 1 + pass 2 ----------------
 __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __restrict__ colsum, int blocks_per_stat, int C, int G, float eps,
-                                                               float* __restrict__ stats, int nstat) {
+                                                               float* __restrict__ stats, int nstat, int rows) {
     // one WORKGROUP per (stat, group): a 5-D GroupNorm at level 0 has 32 units of 12800 items each, too few and too long for one
     // wave per unit (first version: slower than the statistics pass it replaced)
     __shared__ float red[4][3];
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __re
     for (int i = tid; i < total; i += 256) {
         const int rb = i / cpg, c = grp * cpg + (i - rb * cpg);
         const f32x2 sq = *(const f32x2*)(colsum + (((long)stat * blocks_per_stat + rb) * C + c) * 2);
-        const float mb = sq[0] * (1.0f / 32.0f);
-        chan_merge(n, mean, m2, 32.f, mb, fmaxf(sq[1] - sq[0] * mb, 0.f));
+        const float mb = sq[0] / (float)rows;        // one item = `rows` output rows of one channel (32: first-generation GEMM tiles; the wave tile's rows otherwise)
+        chan_merge(n, mean, m2, (float)rows, mb, fmaxf(sq[1] - sq[0] * mb, 0.f));
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -332,9 +332,10 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     const size_t smem = (size_t)256 * 2 * EPC * 4 + (size_t)2 * p.C * 4;
     const int nstat = p.F / p.frames_per_stat;
     float* stats = part + (size_t)p.F * nchunk * p.groups * 3;
-    if (p.colsum) {     // statistics already summed per 32-row block by the producing GEMM's epilogue: no pass over x
-        hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nstat * p.groups), dim3(256), 0, s, p.colsum, p.frames_per_stat * (p.HW / 32),
-                           p.C, p.groups, p.eps, stats, nstat);
+    if (p.colsum) {     // statistics already summed per block of `colsum_rows` rows by the producing GEMM's epilogue: no pass over x
+        const int crows = p.colsum_rows > 0 ? p.colsum_rows : 32;
+        hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nstat * p.groups), dim3(256), 0, s, p.colsum, (p.frames_per_stat * p.HW) / crows,
+                           p.C, p.groups, p.eps, stats, nstat, crows);
         GEO4D_CHECK_LAUNCH();
     } else {
         hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, p.F), dim3(256), smem, s, (const T*)p.x, (long)p.ldx, p.HW, p.C, p.groups,
@@ -389,7 +390,13 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
     if ((p.ldx * esz) % 16 || (p.ldy * esz) % 16 || ((uintptr_t)p.x % 16) || ((uintptr_t)p.y % 16)) { geo4d_set_error("groupnorm: alignment"); return GEO4D_EINVAL; }
     if (p.workspace_bytes < geo4d_groupnorm_workspace(p.F, p.HW, p.groups, p.frames_per_stat)) { geo4d_set_error("groupnorm: workspace too small"); return GEO4D_EINVAL; }
     if (p.F > 65535) { geo4d_set_error("groupnorm: too many frames"); return GEO4D_EINVAL; }
-    if (p.colsum && ((p.HW % 32) || ((uintptr_t)p.colsum % 8))) { geo4d_set_error("groupnorm: colsum needs HW % 32 == 0"); return GEO4D_EINVAL; }
+    {
+        const int crows = p.colsum_rows > 0 ? p.colsum_rows : 32;      // blocks must not straddle two statistics
+        if (p.colsum && ((((long)p.frames_per_stat * p.HW) % crows) || ((uintptr_t)p.colsum % 8))) {
+            geo4d_set_error("groupnorm: colsum needs (frames_per_stat x HW) % colsum_rows == 0");
+            return GEO4D_EINVAL;
+        }
+    }
     if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8))) { geo4d_set_error("groupnorm: split_out is the bf16x3 producer format: f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {

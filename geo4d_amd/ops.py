@@ -115,10 +115,11 @@ _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1
                (71, 5), (73, 5), (74, 5), (73, 6), (74, 6), (73, 8), (74, 8), (73, 10), (74, 10)]
 _VALID_HINTS = {t for t, _ in _CANDIDATES} | {0}
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
-# GEMM epilogues can emit the next GroupNorm's column sums (gn_stats=True call sites). OFF by default: measured on MI355X the fused
-# path is correct but not faster yet (round 2: -3.5 % bf16x3, -7 % bf16 with the first finalize kernel) - the epilogue work lands on
-# every producing GEMM while the 5-D GroupNorms' merge over 12800 items per group is latency-bound; kept behind the switch for A/B.
-GN_FUSED_STATS = _os.environ.get("GEO4D_GN_FUSED", "0") != "0"
+# GEMM epilogues can emit the next GroupNorm's column sums (gn_stats=True call sites), which removes that GroupNorm's statistics pass
+# over the tensor. 1 (default since round 4): where the second / third generation's fast epilogue does it per wave-tile row range at
+# ~0.3 us per tile (f32 rows, i.e. the bf16x3 mode: same-box A/B +1.2 % frames/s, decode -2.5 %, profiles/r04_gn_fused_stats.md);
+# 2: also on the first-generation tiles (round 2: measured slower there: -3.5 % bf16x3, -7 % bf16); 0: off.
+GN_FUSED_STATS = int(_os.environ.get("GEO4D_GN_FUSED", "1"))
 TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) of every shape autotuned in this process (tools/tune_gemm.py prints it)
 DEBUG_ABLATE = 0       # tools/gemm_bench.py --ablate only
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
@@ -267,17 +268,19 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
-    if gn_stats and GN_FUSED_STATS and M % 32 == 0 and N % 8 == 0 and act != 2 and not out_nchw and batch == 1 and split_k <= 1 \
-            and out.dim() == 2 and out.shape[0] == M and out.data_ptr() % 16 == 0 and (ldo * out.element_size()) % 16 == 0 \
-            and (residual is None or (residual.data_ptr() % 16 == 0 and (ldr * out.element_size()) % 16 == 0)):
-        # the consumer GroupNorm's statistics pass, for free: per 32-row block and column (sum, sum of squares) from the epilogue
-        split_k = 1
-        if tile_hint >= 21:          # the second-generation tiles have no gn_colsum epilogue
-            tile_hint = 0
-        cs = torch.empty((M // 32, N, 2), device=out.device, dtype=torch.float32)
-        p.gn_colsum = cs.data_ptr()
-        out._gn_colsum = cs
-        out._gn_colsum_tag = (out.data_ptr(), out._version)      # groupnorm() ignores the sums if the buffer was rewritten by torch since
+    if gn_stats and GN_FUSED_STATS and not p.o_split and batch == 1 and out.dim() == 2 and out.shape[0] == M:
+        # the consumer GroupNorm's statistics pass, for free: per row block and column (sum, sum of squares) from the epilogue. The library
+        # says how many rows one entry of THIS launch covers (32 for the first generation, the wave tile's rows for the second / third; 0 =
+        # this configuration cannot emit them - split-K, activations, unaligned rows: the GroupNorm then runs its own pass)
+        p.tile_hint, p.split_k = tile_hint, split_k
+        rows = lib.geo4d_conv_gemm_colsum_rows(C.byref(p)) if (tile_hint >= 21 or int(GN_FUSED_STATS) >= 2) else 0
+        if rows > 0:
+            split_k = split_k or 1           # (the library's own tile choice may not split a launch that emits the sums)
+            cs = torch.empty((M // rows, N, 2), device=out.device, dtype=torch.float32)
+            p.gn_colsum = cs.data_ptr()
+            out._gn_colsum = cs
+            out._gn_colsum_rows = rows
+            out._gn_colsum_tag = (out.data_ptr(), out._version)      # groupnorm() ignores the sums if the buffer was rewritten by torch since
     if GEMM_TIMELINE is not None:     # bench.py's per-launch HIP-event timeline of the dominant kernel (never on while capturing)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -383,7 +386,9 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     cs = getattr(x, "_gn_colsum", None)     # column sums left on this very tensor object by the GEMM that produced it
     if cs is not None and getattr(x, "_gn_colsum_tag", None) != (x.data_ptr(), x._version):
         cs = None                            # the tensor was modified in place (or re-viewed) after the GEMM wrote it: stale sums
-    p.colsum = cs.data_ptr() if (cs is not None and HW % 32 == 0 and tuple(cs.shape) == (F * HW // 32, Cc, 2)) else 0
+    rows = getattr(x, "_gn_colsum_rows", 32)
+    ok = cs is not None and (frames_per_stat * HW) % rows == 0 and tuple(cs.shape) == (F * HW // rows, Cc, 2)
+    p.colsum, p.colsum_rows = (cs.data_ptr(), rows) if ok else (0, 0)
     _lib.check(lib.geo4d_groupnorm(C.byref(p), _stream()), "geo4d_groupnorm")
     return out
 

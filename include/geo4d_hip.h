@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEO4D_ABI_VERSION 5
+#define GEO4D_ABI_VERSION 6
 
 /* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
  * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
@@ -79,12 +79,16 @@ typedef struct geo4d_conv_gemm_t {
                             side of a_split (GEGLU -> FF-out chain; q | k and V^T of the spatial attention, geo4d_attention_t.qkv_split).
                             Stored columns % 8 == 0, ldo % 8 == 0, 32-byte aligned rows, no split-K, any epilogue incl. residual;
                             served by the second- / third-generation tiles (first-generation hints are re-routed) */
-    float* gn_colsum;    /* optional [M/32][N][2] fp32: per 32-row block and output column, (sum, sum of squares) of the values this
+    float* gn_colsum;    /* optional [M/rows][N][2] fp32 (rows = geo4d_conv_gemm_colsum_rows(p): 32 for the first generation): per row block and output column, (sum, sum of squares) of the values this
                             launch stores - the statistics pass of the GroupNorm that consumes O, produced for free by the epilogue
                             (geo4d_groupnorm_t.colsum). Needs M % 32 == 0, N % 8 == 0, row-major 16-byte aligned output, batch 1,
                             no GEGLU and no split-K. */
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);
+/* Rows of the output that ONE gn_colsum entry of the launch `*p` describes covers (tile_hint / split_k as they will be launched, the
+   gn_colsum field itself ignored): 32 for the first-generation tiles, the wave tile's rows (32..128) for tile hints >= 21; 0 = this
+   launch cannot emit the sums. gn_colsum then has [M / rows][N][2] floats. */
+int geo4d_conv_gemm_colsum_rows(const geo4d_conv_gemm_t* p);
 
 /* GroupNorm(groups) [+SiLU] over tokens [F][HW][C]; statistics per (F / frames_per_stat, group) in fp32.
  * replaces nn.GroupNorm / GroupNormSpecific + nn.SiLU (basics.py:76-87; openaimodel3d.py:151-153,174-176,256-266;
@@ -98,10 +102,12 @@ typedef struct geo4d_groupnorm_t {
     int act;             /* 0 none, 1 SiLU / swish                                       */
     int dtype;
     float eps;
-    const float* colsum; /* optional: [F*HW/32][C][2] column sums written by the producing geo4d_conv_gemm (gn_colsum); when given
-                            (needs HW % 32 == 0) the pass over x that computes the statistics is skipped */
+    const float* colsum; /* optional: [F*HW/colsum_rows][C][2] column sums written by the producing geo4d_conv_gemm (gn_colsum); when
+                            given the pass over x that computes the statistics is skipped */
     int split_out;       /* bf16x3 producers (dtype F32 only, C % 8 == 0): y is written in the PRE-SPLIT operand format of
                             geo4d_conv_gemm_t.a_split - per 8 channels [8 x bf16 hi | 8 x bf16 lo]; ldy still counts channels */
+    int colsum_rows;     /* rows per `colsum` entry (what geo4d_conv_gemm_colsum_rows returned for the producing launch); 0 = 32;
+                            (frames_per_stat x HW) % colsum_rows == 0 */
 } geo4d_groupnorm_t;
 size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat);
 int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);

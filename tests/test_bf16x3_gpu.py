@@ -201,3 +201,40 @@ def test_x3_kernels_are_deterministic_on_a_full_chip(dev):
     outs = [ops.conv2d(x, w, None, F=16, Hin=20, Win=32, KH=3, KW=3, pad=1, tile_hint=t, split_k=1)[0] for t in (1, 1, 2, 3, 4, 11, 13, 13, 16, 17)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "conv_gemm (bf16x3) output depends on launch / tile shape"
+
+
+@pytest.mark.parametrize("tile", [22, 23, 25, 27, 28, 71, 72, 73, 74])
+@pytest.mark.parametrize("F,fps", [(2, 1), (2, 2), (1, 1)])       # F = 1: M = 1920 leaves the last row tile of the 256- / 192- / 160-row tiles ragged (waves beyond M write nothing)
+def test_groupnorm_statistics_from_the_fast_epilogue(dev, tile, F, fps):
+    """Round 4: the second / third generation GEMMs' fast epilogue emits the consumer GroupNorm's column sums per WAVE-TILE row range
+    (geo4d_conv_gemm_colsum_rows: 32..128 rows per entry), bias / row-bias table / residual included; the GroupNorm fed by them equals
+    the three-pass GroupNorm and F.group_norm. (Switch off by default, exercised here regardless.)"""
+    import torch.nn.functional as TF
+    from geo4d_amd import ops, pack
+    HW, Cc, K = 1920, 320, 256
+    M = F * HW
+    g = torch.Generator().manual_seed(500 + tile)
+    x, w = torch.randn((M, K), generator=g).to(dev), (torch.randn((Cc, K), generator=g) * 0.1).to(dev)
+    b, r = torch.randn((Cc,), generator=g).to(dev), torch.randn((M, Cc), generator=g).to(dev)
+    emb = torch.randn((F, Cc), generator=g).to(dev)
+    gam, bet = torch.randn((Cc,), generator=g).to(dev), torch.randn((Cc,), generator=g).to(dev)
+    wp = pack.pack_linear(w, "bf16x3")
+    old = ops.GN_FUSED_STATS
+    ops.GN_FUSED_STATS = 2
+    try:
+        for kw in (dict(residual=r), dict(rowbias=emb, rowbias_div=HW), dict()):
+            h = torch.empty((M, Cc), device=dev)
+            ops.conv_gemm(x, wp, h, M=M, N=Cc, K=K, Cin=K, lda=K, ldw=wp.stride(0), ldo=Cc, bias=b, ldr=Cc if "residual" in kw else 0,
+                          tile_hint=tile, split_k=1, gn_stats=True, **kw)
+            rows = getattr(h, "_gn_colsum_rows", 0)
+            assert rows in (32, 64, 80, 96, 128) and h._gn_colsum.shape == (M // rows, Cc, 2), (tile, rows)
+            hf = h.double()
+            cs_ref = torch.stack([hf.reshape(M // rows, rows, Cc).sum(1), (hf ** 2).reshape(M // rows, rows, Cc).sum(1)], -1).float()
+            assert ((h._gn_colsum - cs_ref).norm() / cs_ref.norm()).item() < 2e-6, (tile, list(kw))
+            fused = ops.groupnorm(h, gam, bet, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)
+            plain = ops.groupnorm(h.clone(), gam, bet, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)      # the clone carries no sums
+            x5 = h.reshape(F // fps, fps, HW, Cc).permute(0, 3, 1, 2)
+            ref = TF.silu(TF.group_norm(x5, 32, gam, bet, 1e-5)).permute(0, 2, 3, 1).reshape(M, Cc)
+            assert ((fused - ref).norm() / ref.norm()).item() < 2e-5 and ((fused - plain).norm() / plain.norm()).item() < 1e-5, (tile, list(kw))
+    finally:
+        ops.GN_FUSED_STATS = old

@@ -436,7 +436,7 @@ def test_groupnorm_statistics_from_the_gemm_epilogue(dev, dtype, case):
     writes every (block, column) exactly once; a residual and a bias are part of what is summed."""
     from geo4d_amd import ops
     monkey = ops.GN_FUSED_STATS
-    ops.GN_FUSED_STATS = True                 # the switch is off by default (ops.py): the path is exercised here regardless
+    ops.GN_FUSED_STATS = 2                 # the switch is off by default (ops.py): the path is exercised here regardless
     try:
         _fused_stats_case(dev, dtype, case)
     finally:
@@ -451,7 +451,8 @@ def _fused_stats_case(dev, dtype, case):
     b, r = rnd((Cc,), dev, torch.float32, 302), rnd((M, Cc), dev, dtype, 303)
     g, be = rnd((Cc,), dev, torch.float32, 304), rnd((Cc,), dev, torch.float32, 305)
     h = ops.linear(x, w, b, residual=r, tile_hint=tile, gn_stats=True)
-    assert hasattr(h, "_gn_colsum") and h._gn_colsum.shape == (M // 32, Cc, 2)
+    rows = h._gn_colsum_rows
+    assert rows == 32 and hasattr(h, "_gn_colsum") and h._gn_colsum.shape == (M // rows, Cc, 2)      # (first-generation tiles: 32-row blocks)
     cs_ref = torch.stack([h.float().reshape(M // 32, 32, Cc).sum(1), (h.float() ** 2).reshape(M // 32, 32, Cc).sum(1)], -1)
     assert rel(h._gn_colsum, cs_ref) < (2e-3 if dtype == torch.bfloat16 else 3e-4)      # sums of the un-rounded fp32 values
     fused = ops.groupnorm(h, g, be, F=F, HW=HW, eps=1e-5, frames_per_stat=fps, silu=True)

@@ -98,6 +98,14 @@ case $JOB in
     timeout 500 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-420 $O/bench.json
     timeout 600 python bench.py --clip-frames 64 --no-cpu-baseline > $O/clip64.json 2> $O/clip64.err; tail -2 $O/clip64.err; cut -c1-2400 $O/clip64.json
     ;;
+  r4k)         # GroupNorm statistics from the fast epilogue (GEO4D_GN_FUSED=1): correct? faster? (A/B on one box, default stays off)
+    ( time timeout 600 python -m pytest tests/test_bf16x3_gpu.py tests/test_kernels_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_presplit_gpu.py -m gpu -q -x -k "statistics or groupnorm or gemm or conv or linear or epilogue" --durations=3 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error" $O/pytest.log | tail -6
+    for f in 0 1 0 1; do
+      GEO4D_GN_FUSED=$f timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench_fused$f.json 2> $O/bench_fused$f.err
+      python -c "import json; d=json.load(open('$O/bench_fused$f.json')); print('GN_FUSED=$f', round(d['value'],3), {k:round(v) for k,v in d['split_ms_per_step'].items()})" || tail -3 $O/bench_fused$f.err
+    done
+    ;;
   tests)       # gpu test files given as arguments (default: all)
     ( time timeout 1200 python -m pytest ${@:-tests} -m gpu -q -x --durations=8 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
     grep -E "passed|failed|rc=|Error" $O/pytest.log | tail -8
