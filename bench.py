@@ -203,13 +203,15 @@ def synthetic_scene_maps(slices, T, H, W, dev):
     return maps, traj
 
 
-def clip_mode(args, model, pvae, dev, rank, world):
+def clip_mode(args, model, pvae, dev, rank, world, clip_kw=None, align_fn=None):
     """`--clip-frames N`: ONE synthetic N-frame clip end to end, the way the reference's evaluation entry times it
     (scripts/evaluation/infer_geo4d.py:437-463 window loop, :503-511 alignment): sliding 16-frame windows (stride 4, tail window
     appended: 64 frames -> 14 windows, 128 -> 30; BASELINE.json configs[2] / [3]) round-robin over the ranks, per window VAE encode +
     S-step DDIM + 4-modality decode (frame-sharded over the ranks when N > 1) + Plücker cameras, all-gather of the decoded clip, then
     `post_optimization` (init + 500 Adam iterations, window blocks sharded over the ranks with one all-reduce per iteration).
-    STRONG scaling: the clip is fixed, ranks divide it. Returns the JSON dict (rank 0) with per-phase seconds."""
+    STRONG scaling: the clip is fixed, ranks divide it. Returns the JSON dict (rank 0) with per-phase seconds.
+    `clip_kw` (extra run_clip arguments) and `align_fn` (stands in for post_optimization) exist for the world-2 gloo test of this very
+    function on CPU (tests/test_dist_cpu.py: stub denoiser / decoder / aligner, the real window sharding, gathers, barriers and timers)."""
     from geo4d_amd.align import post_optimization
     from geo4d_amd.pipeline import run_clip, window_slices
     N, H, W = args.clip_frames, args.height, args.width
@@ -218,22 +220,26 @@ def clip_mode(args, model, pvae, dev, rank, world):
     ctx = torch.randn((1, 77 + 16 * 16, 1024), generator=g).to(dev)
     kw = dict(pointmap_vae=pvae, ddim_steps=args.ddim_steps, ddim_eta=0.0, seed=123, with_cameras=True,
               decode="sharded" if world > 1 else "local")
+    kw.update(clip_kw or {})
+    cuda = dev.type == "cuda"
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if cuda:
+            torch.cuda.synchronize()
     run_clip(model, video[:, :, :16], ctx, **dict(kw, decode="local", gather=False) if world == 1 else kw)     # warm-up: tuning, graph capture, allocator
     barrier()
     t0 = time.perf_counter()
-    slices, maps, traj = run_clip(model, video, ctx, **kw)
+    out = run_clip(model, video, ctx, **kw)
+    slices, maps, traj = out[0], out[1], (out[2] if len(out) > 2 else None)
     barrier()
     t1 = time.perf_counter()
     if not args.clip_align_on_noise:     # (untimed) the alignment phases run on a consistent synthetic scene of the same shapes: see synthetic_scene_maps
         maps, traj = synthetic_scene_maps(slices, 16, H, W, dev)
     barrier()
     t1b = time.perf_counter()
-    scene = post_optimization(slices, maps, traj, dict(n_iter=args.align_iters, pose_schedule="linear", temporal_smoothing_weight=0.015,
+    scene = (align_fn or post_optimization)(slices, maps, traj, dict(n_iter=args.align_iters, pose_schedule="linear", temporal_smoothing_weight=0.015,
                                                       translation_weight=1.0), align=False)
     barrier()
     t2 = time.perf_counter()

@@ -264,3 +264,63 @@ def test_alignment_shard_falls_back_when_windows_fewer_than_ranks():
     import inspect
     from geo4d_amd import align
     assert "owns no window" in inspect.getsource(align.GroupAligner.__init__)
+
+
+class _StubScene:
+    """Stands in for GroupAligner in the world-2 test of bench.clip_mode: the real one needs the HIP kernels. Its optimisation does what
+    the sharded alignment does per iteration - one all-reduce over the ranks."""
+    def __init__(self, n_img, H, W):
+        self.depth, self.poses = torch.ones((n_img, H * W)), torch.eye(4).repeat(n_img, 1, 1)
+
+    def compute_global_alignment(self, niter, schedule, lr):
+        for _ in range(niter):
+            t = torch.ones(4)
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(t)
+            self.depth += 0.0 * t[0]
+
+    def get_depthmaps(self):
+        return self.depth
+
+    def get_im_poses_matrix(self):
+        return self.poses
+
+
+def _stub_align(slices, maps, traj, args, align=True):
+    assert maps.shape[1:3] == (11, 16) and torch.isfinite(maps).all() and traj is not None and traj.shape[:2] == maps.shape[:1] + (16,)
+    return _StubScene(1 + max(s.stop - 1 for s in slices), maps.shape[3], maps.shape[4])
+
+
+def _bench_clip_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import argparse
+    import bench
+    from geo4d_amd import dist as gd
+    gd.init_from_env(backend="gloo")
+    args = argparse.Namespace(clip_frames=22, height=32, width=64, ddim_steps=2, align_iters=5, clip_align_on_noise=False, dtype="bf16x3", no_graph=False)
+    res = bench.clip_mode(args, _StubModel, None, torch.device("cpu"), rank, world,
+                          clip_kw=dict(synthesize=_stub_synth, decoder=_stub_decoder, with_cameras=False), align_fn=_stub_align)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_clip_mode_world2_protocol():
+    """bench.py --clip-frames under two gloo ranks on CPU: the SAME function the GPU run calls (window sharding, frame-sharded decode,
+    gathers, the untimed synthetic-scene hand-over, barriers on both sides of every phase, MAX over ranks of the phase seconds), with a
+    stub denoiser / decoder / aligner in place of the HIP kernels. Rank 0 returns the strong-scaling line, the other rank nothing."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_clip_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=240) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    assert res[1] is None
+    line = res[0]
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["windows"] == 3 and line["config"]["windows_per_rank_max"] == 2
+    ph = line["phase_seconds"]
+    assert set(ph) == {"denoise_decode_gather", "alignment_init", "alignment_5_iterations", "total"}
+    assert abs(ph["total"] - (ph["denoise_decode_gather"] + ph["alignment_init"] + ph["alignment_5_iterations"])) < 0.5 * ph["total"] + 1e-3
+    assert abs(line["value"] - 22 / ph["total"]) < 1e-9 and line["alignment_outputs_finite"] is True
+    assert "frame-sharded VAE decode" in line["config"]["parallelism"]
