@@ -274,13 +274,13 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         # this configuration cannot emit them - split-K, activations, unaligned rows: the GroupNorm then runs its own pass)
         p.tile_hint, p.split_k = tile_hint, split_k
         rows = lib.geo4d_conv_gemm_colsum_rows(C.byref(p)) if (tile_hint >= 21 or int(GN_FUSED_STATS) >= 2) else 0
-        if rows == 0 and int(GN_FUSED_STATS) >= 2 and tile_hint >= 21:
-            # mode 2 (A/B, tests): a second / third generation choice that cannot emit the sums (16-bit rows, split-K) gives way to the
-            # library's own first-generation choice, as this path did before round 4
-            p.tile_hint, p.split_k = 0, 1
+        if rows == 0 and int(GN_FUSED_STATS) >= 2:
+            # mode 2 (A/B, tests): a tuned configuration that cannot emit the sums (split-K; a second / third generation tile on 16-bit rows)
+            # gives way to an un-split first-generation launch, as this path did before round 4
+            p.tile_hint, p.split_k = (tile_hint if tile_hint < 21 else 0), 1
             rows = lib.geo4d_conv_gemm_colsum_rows(C.byref(p))
             if rows > 0:
-                tile_hint, split_k = 0, 1
+                tile_hint, split_k = p.tile_hint, 1
         if rows > 0:
             split_k = split_k or 1           # (the library's own tile choice may not split a launch that emits the sums)
             cs = torch.empty((M // rows, N, 2), device=out.device, dtype=torch.float32)
