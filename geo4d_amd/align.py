@@ -94,7 +94,9 @@ def rigid_points_registration(x, y, weights):
     xc, yc = x - xm, y - ym
     # 3 x 3 weighted covariance as nine fp64 sums: `(w yc)^T @ xc` hands rocBLAS a dgemm with M = N = 3 and K = millions of points, which
     # took 64 ms per window at 16 x 320 x 512 (59 calls = 3.8 of the 3.9 s of a 128-frame clip's alignment init, tools/align_init_profile.py)
-    cov = ((w[:, None] * yc).unsqueeze(2) * xc.unsqueeze(1)).sum(0)
+    # (row by row: three [N, 3] temporaries instead of one [N, 3, 3] = 190 MB per 16 x 320 x 512 window)
+    wy = w[:, None] * yc
+    cov = torch.stack([(wy[:, i:i + 1] * xc).sum(0) for i in range(3)])
     U, S, Vt = torch.linalg.svd(cov.cpu())
     d = torch.sign(torch.det(U @ Vt))
     D = torch.diag(torch.stack([torch.ones(()).double(), torch.ones(()).double(), d]))

@@ -111,14 +111,72 @@ def inference(pairs, model, device, batch_size=8, verbose=True):
     return collate_with_cat(chunks, lists=ragged)
 
 
+def _rigid_apply(pose, pts):
+    """dust3r/utils/geometry.py:40-112 `geotrf` for the case get_pred_pts3d needs: `pose` [..., 3|4, 3|4] applied to points
+    [..., h, w, 3] (leading batch dimensions equal): x -> R x + t."""
+    d = pts.shape[-1]
+    pose = pose.to(pts.dtype)
+    lead = pose.shape[:-2]
+    if tuple(pts.shape[:len(lead)]) != tuple(lead):
+        raise ValueError(f"camera_pose batch {tuple(lead)} does not match the points {tuple(pts.shape)}")
+    flat = pts.reshape(*lead, -1, d)
+    out = flat @ pose[..., :d, :d].transpose(-1, -2)
+    if pose.shape[-1] == d + 1:
+        out = out + pose[..., None, :d, d]
+    elif pose.shape[-1] != d:
+        raise ValueError(f"bad transform shape {tuple(pose.shape)} for {d}-D points")
+    return out.reshape(pts.shape)
+
+
+def depthmap_to_pts3d(depth, pseudo_focal, pp=None, **_):
+    """dust3r/utils/geometry.py:114-162: unproject a z-depth map [B,H,W] (or [B,H,W,n]) with per-pixel pseudo focals ([B,H,W],
+    [B,1,H,W] or [B,2,H,W]) around the principal point `pp` [B,2] (default: the image centre (W-1)/2, (H-1)/2)."""
+    B, H, W = depth.shape[:3]
+    if pseudo_focal.ndim == 3:
+        fx = fy = pseudo_focal
+    elif pseudo_focal.ndim == 4:
+        fx = pseudo_focal[:, 0]
+        fy = pseudo_focal[:, 1] if pseudo_focal.shape[1] == 2 else fx
+    else:
+        raise NotImplementedError("Error, unknown input focal shape format.")
+    assert fx.shape == depth.shape[:3] and fy.shape == depth.shape[:3]
+    u = torch.arange(W, device=depth.device).view(1, 1, W).expand(1, H, W)
+    v = torch.arange(H, device=depth.device).view(1, H, 1).expand(1, H, W)
+    if pp is None:
+        u, v = u - (W - 1) / 2, v - (H - 1) / 2
+    else:
+        u, v = u - pp[:, 0, None, None], v - pp[:, 1, None, None]
+    if depth.ndim == 3:
+        pts = torch.empty((B, H, W, 3), device=depth.device)
+        pts[..., 0], pts[..., 1], pts[..., 2] = depth * u / fx, depth * v / fy, depth
+    else:
+        pts = torch.empty((B, H, W, 3, depth.shape[3]), device=depth.device)
+        pts[..., 0, :], pts[..., 1, :], pts[..., 2, :] = depth * (u / fx)[..., None], depth * (v / fy)[..., None], depth
+    return pts
+
+
 def get_pred_pts3d(gt, pred, use_pose=False):
-    """dust3r/inference.py:110-132 (point-map branch)."""
-    if "pts3d" in pred:
-        return pred["pts3d"]
-    if "pts3d_in_other_view" in pred:
+    """dust3r/inference.py:110-132, all three branches: depth + pseudo_focal heads are unprojected (principal point from
+    gt['camera_intrinsics'] when present), a `pts3d` head is returned as is, and either goes through pred['camera_pose'] when
+    `use_pose`; `pts3d_in_other_view` is already in the other camera's frame (use_pose must be set)."""
+    if "depth" in pred and "pseudo_focal" in pred:
+        try:
+            pp = gt["camera_intrinsics"][..., :2, 2]
+        except KeyError:
+            pp = None
+        pts3d = depthmap_to_pts3d(**pred, pp=pp)
+    elif "pts3d" in pred:
+        pts3d = pred["pts3d"]
+    elif "pts3d_in_other_view" in pred:
         assert use_pose is True
         return pred["pts3d_in_other_view"]
-    raise NotImplementedError("depth + pseudo_focal unprojection is part of the DUSt3R head, not of Geo4D")
+    else:
+        raise KeyError("pred holds none of depth + pseudo_focal, pts3d, pts3d_in_other_view")
+    if use_pose:
+        camera_pose = pred.get("camera_pose")
+        assert camera_pose is not None
+        pts3d = _rigid_apply(camera_pose, pts3d)
+    return pts3d
 
 
 def find_opt_scaling(gt_pts1, gt_pts2, pr_pts1, pr_pts2=None, fit_mode="weiszfeld_stop_grad", valid1=None, valid2=None):

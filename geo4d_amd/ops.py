@@ -99,7 +99,12 @@ WORKSPACE_BYTES = 256 << 20
 # problem-signature -> (tile_hint, split_k): loaded from geo4d_amd/tuning/gfx950.json (measured on MI355X by
 # tools/tune_gemm.py) and, for shapes not in it, filled by timing the candidates on first eager use (never while a
 # hipGraph is being captured). Every candidate computes the same sums in the same k order per output element
-# (split-K only regroups them), so tuning never changes results beyond fp32 re-association.
+# (split-K only regroups them), so tuning never changes a GEMM's result beyond fp32 re-association. Since round 4 (GN_FUSED_STATS = 1)
+# the tile choice ALSO sets the row granularity of the GroupNorm statistics its epilogue emits (32 ... 128 rows per entry), so the
+# consumer GroupNorm - and with it the U-Net output - differs at fp32 round-off between tile choices: bit-reproducibility holds PER
+# TUNING TABLE (the committed gfx950.json + whatever this process measured for shapes missing from it), not per candidate. Processes
+# that must agree bit for bit (ranks comparing outputs, a captured graph against a later eager run of a shape first met during capture)
+# need the same table: ship one (save_tuning) or set GEO4D_AUTOTUNE=0 / GEO4D_GN_FUSED=0.
 import json as _json
 import os as _os
 
@@ -119,7 +124,19 @@ AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"
 # over the tensor. 1 (default since round 4): where the second / third generation's fast epilogue does it per wave-tile row range at
 # ~0.3 us per tile (f32 rows, i.e. the bf16x3 mode: same-box A/B +1.2 % frames/s, decode -2.5 %, profiles/r04_gn_fused_stats.md);
 # 2: also on the first-generation tiles (round 2: measured slower there: -3.5 % bf16x3, -7 % bf16); 0: off.
-GN_FUSED_STATS = int(_os.environ.get("GEO4D_GN_FUSED", "1"))
+def _env_level(name, default):
+    """0 / 1 / 2 ... or the usual words: off / false / no -> 0, on / true / yes (and anything else that is not a number) -> 1."""
+    v = _os.environ.get(name)
+    if v is None or not v.strip():
+        return default
+    v = v.strip().lower()
+    try:
+        return int(v)
+    except ValueError:
+        return 0 if v in ("off", "false", "no", "none") else 1
+
+
+GN_FUSED_STATS = _env_level("GEO4D_GN_FUSED", 1)
 TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) of every shape autotuned in this process (tools/tune_gemm.py prints it)
 DEBUG_ABLATE = 0       # tools/gemm_bench.py --ablate only
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
@@ -195,6 +212,10 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     operands: f32 activations against a pre-split bf16 weight (either side), or two f32 operands with `x3=True`."""
     lib = _lib.load()
     _dev(a, "A", True); _dev(w, "W", True); _dev(out, "out", True)
+    if getattr(out, "_gn_colsum", None) is not None:       # sums of an EARLIER launch into this tensor object: this launch either sets fresh ones or leaves none
+        out._gn_colsum = None
+        out._gn_colsum_rows = 32
+        out._gn_colsum_tag = None
     for opt, nm in ((bias, "bias"), (rowbias, "rowbias"), (residual, "residual")):
         if opt is not None:
             _dev(opt, nm)

@@ -208,7 +208,7 @@ def test_x3_kernels_are_deterministic_on_a_full_chip(dev):
 def test_groupnorm_statistics_from_the_fast_epilogue(dev, tile, F, fps):
     """Round 4: the second / third generation GEMMs' fast epilogue emits the consumer GroupNorm's column sums per WAVE-TILE row range
     (geo4d_conv_gemm_colsum_rows: 32..128 rows per entry), bias / row-bias table / residual included; the GroupNorm fed by them equals
-    the three-pass GroupNorm and F.group_norm. (Switch off by default, exercised here regardless.)"""
+    the three-pass GroupNorm and F.group_norm. (Mode 2 = also on first-generation tiles; the default since round 4 is 1: second / third generation producers only.)"""
     import torch.nn.functional as TF
     from geo4d_amd import ops, pack
     HW, Cc, K = 1920, 320, 256

@@ -68,3 +68,94 @@ def test_symmetrized_batch_and_loss_hook():
     res = di.loss_of_one_batch((v1, v2), StubModel(), lambda a, b, p1, p2: p1["pts3d"].sum() * 0 + 7.0, "cpu", symmetrize_batch=True)
     assert float(res["loss"]) == 7.0 and res["pred1"]["pts3d"].shape[0] == 4
     assert di.loss_of_one_batch((v1, v2), StubModel(), None, "cpu", ret="pred2")["pts3d_in_other_view"].shape[0] == 2
+
+
+def _reference_get_pred_pts3d():
+    """The reference's own function (build container only: /root/reference is absent on the GPU box), or None."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    root = "/root/reference"
+    if not os.path.isdir(root):
+        return None
+    saved = {k: sys.modules.get(k) for k in ("dust3r", "dust3r.utils", "dust3r.utils.device", "dust3r.utils.misc", "dust3r.utils.geometry",
+                                            "dust3r.viz", "dust3r.utils.image", "tqdm")}
+    try:
+        for name in ("dust3r", "dust3r.utils"):
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(root, *name.split("."))]
+            sys.modules[name] = m
+        viz, img = types.ModuleType("dust3r.viz"), types.ModuleType("dust3r.utils.image")       # plotting / image helpers: not on this path
+        viz.SceneViz = viz.auto_cam_size = img.rgb = None
+        sys.modules["dust3r.viz"], sys.modules["dust3r.utils.image"] = viz, img
+        misc = types.ModuleType("dust3r.utils.misc")          # the real one drags cv2 / evo in at module level; these two are not called here
+        misc.invalid_to_nans = misc.invalid_to_zeros = None
+        sys.modules["dust3r.utils.misc"] = misc
+        if saved["tqdm"] is None:
+            try:
+                import tqdm  # noqa: F401
+            except ImportError:
+                t = types.ModuleType("tqdm")
+                t.tqdm = lambda x, **k: x
+                sys.modules["tqdm"] = t
+        spec = importlib.util.spec_from_file_location("dust3r.inference", os.path.join(root, "dust3r", "inference.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.get_pred_pts3d
+    except Exception:
+        return None
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_get_pred_pts3d_all_branches_match_the_reference():
+    """`use_pose` goes through camera_pose (it used to return the untransformed points) and the
+    depth + pseudo_focal branch exists. Expectations are closed-form; where /root/reference is importable the reference's own
+    get_pred_pts3d (dust3r/inference.py:110-132) is run beside ours on the same inputs."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 5, 7
+    pts = torch.randn((B, H, W, 3), generator=g)
+    ang = torch.tensor([0.3, -1.1])
+    pose = torch.eye(4).repeat(B, 1, 1)
+    pose[:, 0, 0], pose[:, 0, 2], pose[:, 2, 0], pose[:, 2, 2] = ang.cos(), ang.sin(), -ang.sin(), ang.cos()
+    pose[:, :3, 3] = torch.randn((B, 3), generator=g)
+    depth = torch.rand((B, H, W), generator=g) + 0.5
+    focal2 = torch.rand((B, 2, H, W), generator=g) * 50 + 100
+    K = torch.eye(3).repeat(B, 1, 1)
+    K[:, 0, 2], K[:, 1, 2] = torch.tensor([3.2, 2.9]), torch.tensor([2.1, 1.7])
+    cases = [({}, {"pts3d": pts}, False), ({}, {"pts3d": pts, "camera_pose": pose}, True),
+             ({}, {"depth": depth, "pseudo_focal": focal2[:, 0]}, False),
+             ({"camera_intrinsics": K}, {"depth": depth, "pseudo_focal": focal2, "camera_pose": pose}, True),
+             ({"camera_intrinsics": K}, {"depth": depth, "pseudo_focal": focal2[:, :1]}, False),
+             ({}, {"pts3d_in_other_view": pts, "camera_pose": pose}, True)]
+    ref = _reference_get_pred_pts3d()
+    for gt, pred, use_pose in cases:
+        got = di.get_pred_pts3d(gt, pred, use_pose=use_pose)
+        if "pts3d_in_other_view" in pred:
+            want = pts
+        else:
+            if "depth" in pred:
+                f = pred["pseudo_focal"]
+                fx = f if f.ndim == 3 else f[:, 0]
+                fy = f if f.ndim == 3 else (f[:, 1] if f.shape[1] == 2 else f[:, 0])
+                cx = gt["camera_intrinsics"][:, 0, 2].view(B, 1, 1) if gt else torch.full((B, 1, 1), (W - 1) / 2)
+                cy = gt["camera_intrinsics"][:, 1, 2].view(B, 1, 1) if gt else torch.full((B, 1, 1), (H - 1) / 2)
+                u, v = torch.arange(W).view(1, 1, W) - cx, torch.arange(H).view(1, H, 1) - cy
+                want = torch.stack([depth * u / fx, depth * v / fy, depth], -1)
+            else:
+                want = pts
+            if use_pose:
+                want = torch.einsum("bij,bhwj->bhwi", pose[:, :3, :3], want) + pose[:, None, None, :3, 3]
+        assert torch.allclose(got, want, atol=1e-5), (list(pred), use_pose)
+        if ref is not None:
+            assert torch.allclose(got, ref(gt, pred, use_pose=use_pose), atol=1e-6), (list(pred), use_pose)
+    import pytest
+    with pytest.raises(AssertionError):
+        di.get_pred_pts3d({}, {"pts3d": pts}, use_pose=True)           # camera_pose missing: the reference asserts
+    with pytest.raises(AssertionError):
+        di.get_pred_pts3d({}, {"pts3d_in_other_view": pts}, use_pose=False)

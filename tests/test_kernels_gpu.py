@@ -436,7 +436,7 @@ def test_groupnorm_statistics_from_the_gemm_epilogue(dev, dtype, case):
     writes every (block, column) exactly once; a residual and a bias are part of what is summed."""
     from geo4d_amd import ops
     monkey = ops.GN_FUSED_STATS
-    ops.GN_FUSED_STATS = 2                 # the switch is off by default (ops.py): the path is exercised here regardless
+    ops.GN_FUSED_STATS = 2                 # mode 2: also on first-generation tiles (default 1 = second / third generation producers only, ops.py)
     try:
         _fused_stats_case(dev, dtype, case)
     finally:
