@@ -13,9 +13,9 @@ import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GEO4D_HIP_LIB: load another build of the SAME library (A/B builds of a kernel: tools/gpu_r2k.sh); the ABI handshake below still applies
 LIB_PATH = os.environ.get("GEO4D_HIP_LIB") or os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
-F32, BF16, F16, BF16X3 = 0, 1, 2, 3
+F32, BF16, F16, BF16X3, F16X2 = 0, 1, 2, 3, 4
 
 
 class Geo4DNativeError(RuntimeError):

@@ -21,6 +21,8 @@
 #define GEO4D_BF16 1
 #define GEO4D_F16 2
 #define GEO4D_BF16X3 3   // f32 STORAGE, bf16 MFMA on a 3-term hi/lo split (x_hi.w_hi + x_hi.w_lo + x_lo.w_hi): ~16-bit mantissas
+#define GEO4D_F16X2 4    // conv_gemm only, PRE-SPLIT operands only: [8 x f16 hi | 8 x f16 lo] per 8 K-elements; product = a_hi.w_hi + a_hi.w_lo
+                         // (two f16 MFMAs): the activation carries 11 mantissa bits, the weight ~22 (round 5, the long-K 3x3 convolutions)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,6 +41,12 @@ struct f16_t { unsigned short v; };
 // split once at pack time and stored per 8 K-elements as [8 x bf16 hi | 8 x bf16 lo] (two 16-byte chunks = the same 32 bytes
 // 8 f32 would take), so a fragment read is the same two ds_read_b128 for both layouts.
 struct bf16x3_t { float v; };
+// "f16x2" (round 5): the same 4 bytes per K element and the same [8 hi | 8 lo] grouping, with f16 halves, and only the activation's
+// HI half is multiplied: a.w ~ a_hi.w_hi + a_hi.w_lo - two f16 MFMAs per product instead of three bf16 ones. The activation is an f16
+// (11 bits), the weight hi + lo ~22 bits (pre-scaled by a power of two at pack time so that lo stays out of the f16 subnormals; the
+// launch's alpha undoes the scale). Why that is enough for the long-K 3x3 convolutions and only for them: tests/precision_sim.py,
+// tests/test_precision_floor.py (point-map drift 1.3e-4 .. 2.9e-4 where a full f16 pass costs 2e-3).
+struct f16x2p_t { float v; };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
@@ -89,8 +97,19 @@ template <> struct Elem<bf16x3_t> {
     __device__ static __forceinline__ float ld(const bf16x3_t* p) { return p->v; }
     __device__ static __forceinline__ void st(bf16x3_t* p, float v) { p->v = v; }
 };
+template <> struct Elem<f16x2p_t> {
+    static constexpr int EPC = 4;      // 4 bytes per K element, like bf16x3
+    static constexpr int DT = GEO4D_F16X2;
+    __device__ static __forceinline__ float ld(const f16x2p_t* p) { return p->v; }
+    __device__ static __forceinline__ void st(f16x2p_t* p, float v) { p->v = v; }
+};
+// IsX3: the 4-byte split-operand LAYOUT family (LDS swizzle, fragment chunks 2q / 2q + 1, f32 rows in the epilogue); IsTwoPass: of
+// that family, the f16 form that multiplies only the activation's hi half
 template <typename T> struct IsX3 { static constexpr bool value = false; };
 template <> struct IsX3<bf16x3_t> { static constexpr bool value = true; };
+template <> struct IsX3<f16x2p_t> { static constexpr bool value = true; };
+template <typename T> struct IsTwoPass { static constexpr bool value = false; };
+template <> struct IsTwoPass<f16x2p_t> { static constexpr bool value = true; };
 
 // ---- chunk <-> float conversion -----------------------------------------------------------
 template <typename T> __device__ __forceinline__ void chunk_to_f32(const u32x4& c, float* out);
@@ -178,6 +197,19 @@ __device__ __forceinline__ void store_split4(void* row_base, int cc, const float
     const unsigned int h0 = f32x2_to_bf16x2(e[0], e[1]), h1 = f32x2_to_bf16x2(e[2], e[3]);
     const unsigned int l0 = f32x2_to_bf16x2(e[0] - __uint_as_float(h0 << 16), e[1] - __uint_as_float(h0 & 0xffff0000u));
     const unsigned int l1 = f32x2_to_bf16x2(e[2] - __uint_as_float(h1 << 16), e[3] - __uint_as_float(h1 & 0xffff0000u));
+    char* g = (char*)row_base + (cc >> 1) * 32 + (cc & 1) * 8;
+    *(u32x2*)g = u32x2{h0, h1};
+    *(u32x2*)(g + 16) = u32x2{l0, l1};
+}
+// the f16x2 producers' form of store_split4: f16 hi | f16 lo (the consumer GEMM reads hi only; lo keeps the format self-describing).
+// Values are clamped to the f16 range first: an overflow would reach the MFMA as inf.
+__device__ __forceinline__ void store_split4_f16(void* row_base, int cc, const float* e) {
+    float c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = fminf(fmaxf(e[j], -65504.0f), 65504.0f);
+    const unsigned int h0 = f32x2_to_f16x2(c[0], c[1]), h1 = f32x2_to_f16x2(c[2], c[3]);
+    const unsigned int l0 = f32x2_to_f16x2(c[0] - f16_bits_to_f32((unsigned short)(h0 & 0xffffu)), c[1] - f16_bits_to_f32((unsigned short)(h0 >> 16)));
+    const unsigned int l1 = f32x2_to_f16x2(c[2] - f16_bits_to_f32((unsigned short)(h1 & 0xffffu)), c[3] - f16_bits_to_f32((unsigned short)(h1 >> 16)));
     char* g = (char*)row_base + (cc >> 1) * 32 + (cc & 1) * 8;
     *(u32x2*)g = u32x2{h0, h1};
     *(u32x2*)(g + 16) = u32x2{l0, l1};

@@ -47,6 +47,10 @@ namespace geo4d_gemm {
 template <typename T> int colsum_rows_v23(const geo4d_conv_gemm_t& p);      // gemm_kernel_v3.h, instantiated in gemm_v3_bf16x3.hip / gemm_v3_bf16.hip
 extern template int colsum_rows_v23<bf16x3_t>(const geo4d_conv_gemm_t&);
 extern template int colsum_rows_v23<bf16_t>(const geo4d_conv_gemm_t&);
+extern template int colsum_rows_v23<f16x2p_t>(const geo4d_conv_gemm_t&);
+// f16x2 (dtype 4) exists on the second / third generation only
+extern template int launch_v2_typed<f16x2p_t>(const geo4d_conv_gemm_t&, hipStream_t);
+extern template int launch_v3_typed<f16x2p_t>(const geo4d_conv_gemm_t&, hipStream_t);
 }  // namespace geo4d_gemm
 using geo4d_gemm::BKC;
 using geo4d_gemm::MAXTAP;
@@ -55,11 +59,20 @@ using geo4d_gemm::launch_typed;
 extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     if (!pp) return GEO4D_EINVAL;
     geo4d_conv_gemm_t p = *pp;
-    const int esz = (p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3) ? 4 : 2;
+    const int esz = (p.dtype == GEO4D_F32 || p.dtype == GEO4D_BF16X3 || p.dtype == GEO4D_F16X2) ? 4 : 2;
     const int epc = 16 / esz;
     const int bk = BKC * epc;
-    if (p.dtype < 0 || p.dtype > 3 || p.out_dtype < 0 || p.out_dtype > 2) { geo4d_set_error("conv_gemm: bad dtype"); return GEO4D_EINVAL; }
-    if (p.dtype != GEO4D_BF16X3 && (p.a_split || p.w_split)) { geo4d_set_error("conv_gemm: a_split / w_split are bf16x3 (dtype 3) options"); return GEO4D_EINVAL; }
+    if (p.dtype < 0 || p.dtype > 4 || p.out_dtype < 0 || p.out_dtype > 2) { geo4d_set_error("conv_gemm: bad dtype"); return GEO4D_EINVAL; }
+    if (p.dtype != GEO4D_BF16X3 && p.dtype != GEO4D_F16X2 && (p.a_split || p.w_split)) { geo4d_set_error("conv_gemm: a_split / w_split are bf16x3 / f16x2 (dtype 3 / 4) options"); return GEO4D_EINVAL; }
+    if (p.dtype == GEO4D_F16X2) {
+        // two-pass f16: pre-split x pre-split operands, plain f32 rows out, second / third generation tiles (0 = a default per shape)
+        if (!p.a_split || !p.w_split || p.o_split || p.out_nchw || p.out_dtype != GEO4D_F32 || (p.tile_hint != 0 && p.tile_hint < 22)) {
+            geo4d_set_error("conv_gemm: f16x2 (dtype 4) needs a_split and w_split, a row-major f32 output, no o_split, and tile hint 0 or >= 22");
+            return GEO4D_EINVAL;
+        }
+        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? 72 : 25;
+        if (p.split_k == 0) p.split_k = 1;
+    }
     if (p.o_split) {
         const int nst = p.act == 2 ? p.N / 2 : p.N;
         if (p.dtype != GEO4D_BF16X3 || p.out_dtype != GEO4D_F32 || !p.a_split || !p.w_split || p.split_k > 1 || p.out_nchw || p.gn_colsum ||
@@ -105,6 +118,7 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
         case GEO4D_F32: return launch_typed<float>(p, s);
         case GEO4D_BF16: return launch_typed<bf16_t>(p, s);
         case GEO4D_BF16X3: return launch_typed<bf16x3_t>(p, s);
+        case GEO4D_F16X2: return p.tile_hint >= 71 ? geo4d_gemm::launch_v3_typed<f16x2p_t>(p, s) : geo4d_gemm::launch_v2_typed<f16x2p_t>(p, s);
         default: return launch_typed<f16_t>(p, s);
     }
 }
@@ -123,5 +137,6 @@ extern "C" int geo4d_conv_gemm_colsum_rows(const geo4d_conv_gemm_t* pp) {
     }
     if (p.dtype == GEO4D_BF16X3) return geo4d_gemm::colsum_rows_v23<bf16x3_t>(p);
     if (p.dtype == GEO4D_BF16) return geo4d_gemm::colsum_rows_v23<bf16_t>(p);
+    if (p.dtype == GEO4D_F16X2) return geo4d_gemm::colsum_rows_v23<f16x2p_t>(p);
     return 0;
 }

@@ -32,6 +32,13 @@ __device__ __forceinline__ void mma16_x3(f32x4& acc, const u32x4& ah, const u32x
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
 }
 
+// f16x2 (two-pass): acc += ah.(bh + bl) - the activation's hi half against both halves of the weight, two f16 MFMAs (lo term first,
+// like mma16_x3; `bh` / `bl` are the MFMA's A side = the weight, `ah` its B side = the activation)
+__device__ __forceinline__ void mma16_x2(f32x4& acc, const u32x4& bh, const u32x4& bl, const u32x4& ah) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, bl), __builtin_bit_cast(f16x8_t, ah), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, bh), __builtin_bit_cast(f16x8_t, ah), acc, 0, 0, 0);
+}
+
 // LDS slot of logical 16-byte chunk c in panel row r = c ^ swz_key<T>(r). ds_read_b128 is served in lane groups
 // {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with lane = 16 * quarter + row, a group holds rows {0-3,12-15} of one quarter and
 // rows {4-11} of the next. 16-bit types read chunk 4h + quarter -> the plain row-pair key keeps the 16 slots distinct; bf16x3 reads
@@ -61,6 +68,9 @@ inline bool colsum_fast_ok(const geo4d_conv_gemm_t& p, int sp) {
     return sp == 1 && p.act == 0 && !p.o_split && !p.out_nchw && p.batch == 1 && p.out_dtype == GEO4D_F32 && (p.N & 3) == 0 && (p.ldo & 3) == 0 &&
            ((uintptr_t)p.O % 16) == 0 && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R % 16) == 0));
 }
+// The two-pass f16 type has no 256x256 instantiation (that tile spills a few registers around its K loop, and the long-K convolutions
+// the type exists for run on the phased tiles): hint 22 means the 160x320 tile there - same bits, every tile sums in the same order.
+template <typename T> inline int v2_effective_hint(int hint) { return (IsTwoPass<T>::value && hint == 22) ? 23 : hint; }
 inline int v2_wave_rows(int hint) { return hint == 22 ? 64 : hint == 23 ? 80 : hint == 25 ? 64 : (hint == 27 || hint == 28) ? 32 : 0; }
 __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes lr of a 16-lane row, fixed order (DPP: xor 1, xor 2, half mirror, mirror)
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
@@ -518,7 +528,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
     auto compute_slab = [&](int buf) {
         const char* abase = smem + (buf * BM + wr * WTM) * PITCH;
         const char* bbase = smem + (2 * BM + buf * BN + wc * WTN) * PITCH;
-        if constexpr (IsX3<T>::value) {
+        if constexpr (IsTwoPass<T>::value) {
+            // f16x2: pre-split operands only; the activation's lo chunk is never read
+            u32x4 ah[MB];
+#pragma unroll
+            for (int a = 0; a < MB; ++a) ah[a] = *(const u32x4*)(abase + a * 16 * PITCH + foff[0]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const u32x4 bh = *(const u32x4*)(bbase + b * 16 * PITCH + foff[0]);
+                const u32x4 bl = *(const u32x4*)(bbase + b * 16 * PITCH + foff[1]);
+#pragma unroll
+                for (int a = 0; a < MB; ++a) mma16_x2(acc[a][b], bh, bl, ah[a]);      // C rows = n, C cols = m
+            }
+        } else if constexpr (IsX3<T>::value) {
             // one 128-byte slab = 32 k = ONE 16x16x32 step; the activation fragments are split once and reused by every column block
             u32x4 ah[MB], al[MB];
 #pragma unroll
@@ -646,6 +668,10 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
         return GEO4D_EINVAL;
     }
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
+    if constexpr (IsTwoPass<T>::value) {       // f16x2: one instantiation per tile (pre-split x pre-split, plain f32 rows out)
+        if (p.o_split || !p.a_split || !p.w_split) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands and writes plain f32 rows"); return GEO4D_EINVAL; }
+        return launch_v2_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
+    } else {
     if constexpr (IsX3<T>::value) {
         if (p.o_split) {
             if (o_split_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
@@ -656,6 +682,7 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
         if (p.w_split && p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
     }
     return launch_v2_kernel<T, BM, BN, WM, WN, 0>(p, splits, stream);
+    }
 }
 
 // tile hints of the second generation (16x16x32 MFMA, register epilogue, persistent workgroups). Round 4 kept the five the measured
@@ -663,7 +690,9 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 //   22: 256x256, 8 waves (64x128 wave tiles)    23: 160x320, 8 waves (80x80)    25: 128x128, 4 waves (64x64)
 //   27: 64x128, 4 waves (32x64)                 28: 64x64, 4 waves (32x32)
 template <typename T>
-int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
+int launch_v2_typed(const geo4d_conv_gemm_t& p_in, hipStream_t stream) {
+    geo4d_conv_gemm_t p = p_in;
+    p.tile_hint = v2_effective_hint<T>(p_in.tile_hint);
     if constexpr (std::is_same<T, float>::value || std::is_same<T, f16_t>::value) {
         geo4d_set_error("conv_gemm: tile hints 22..28 serve bf16 / bf16x3 (the exact-f32 and the f16 modes stay on hints 0..17)");
         return GEO4D_EINVAL;
@@ -686,7 +715,9 @@ int launch_v2_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             return GEO4D_EINVAL;
         }
         switch (p.tile_hint) {
-            case 22: return launch_v2_cfg<T, 256, 256, 4, 2>(p, sp, stream);
+            case 22:
+                if constexpr (IsTwoPass<T>::value) return GEO4D_EINVAL;      // (unreachable: v2_effective_hint)
+                else return launch_v2_cfg<T, 256, 256, 4, 2>(p, sp, stream);
             case 23: return launch_v2_cfg<T, 160, 320, 2, 4>(p, sp, stream);
             case 25: return launch_v2_cfg<T, 128, 128, 2, 2>(p, sp, stream);
             case 27: return launch_v2_cfg<T, 64, 128, 2, 2>(p, sp, stream);

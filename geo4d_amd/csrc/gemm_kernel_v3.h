@@ -35,6 +35,7 @@ namespace geo4d_gemm {
 // the fall-back tiles live in the gemm_v2_*.hip translation units
 extern template int launch_v2_typed<bf16x3_t>(const geo4d_conv_gemm_t&, hipStream_t);
 extern template int launch_v2_typed<bf16_t>(const geo4d_conv_gemm_t&, hipStream_t);
+extern template int launch_v2_typed<f16x2p_t>(const geo4d_conv_gemm_t&, hipStream_t);
 
 template <int BM, int BN>
 constexpr int v3_smem_bytes() { return 2 * (BM + BN) * PITCH; }
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
 #pragma unroll
         for (int a = 0; a < (H ? MB1 : MB0); ++a) {
             fa[H][0][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[0]);
-            fa[H][1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);
+            if constexpr (!IsTwoPass<T>::value) fa[H][1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);     // (f16x2 never multiplies the activation's lo half)
         }
     };
     auto read_B = [&](auto hc, const char* sb) {
@@ -319,7 +320,19 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     auto mma_quadrant = [&](auto hac, auto hbc) {
         constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
         constexpr int MBH = HA ? MB1 : MB0, NBH = HB ? NB1 : NB0, AO = HA ? MB0 : 0, BO = HB ? NB0 : 0;
-        if constexpr (IsX3<T>::value) {
+        if constexpr (IsTwoPass<T>::value) {
+            // f16x2: w.lo x a.hi, then w.hi x a.hi (the order of mma16_x2)
+#pragma unroll
+            for (int term = 0; term < 2; ++term) {
+#pragma unroll
+                for (int b = 0; b < NBH; ++b) {
+#pragma unroll
+                    for (int a = 0; a < MBH; ++a)
+                        acc[AO + a][BO + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[HB][term == 0 ? 1 : 0][b]),
+                                                                                     __builtin_bit_cast(f16x8_t, fa[HA][0][a]), acc[AO + a][BO + b], 0, 0, 0);
+                }
+            }
+        } else if constexpr (IsX3<T>::value) {
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
 #pragma unroll
@@ -483,6 +496,10 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
         return GEO4D_EINVAL;
     }
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
+    if constexpr (IsTwoPass<T>::value) {
+        if (p.o_split || !p.a_split || !p.w_split) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands and writes plain f32 rows"); return GEO4D_EINVAL; }
+        return launch_v3_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
+    } else {
     if constexpr (IsX3<T>::value) {
         if (p.o_split) {
             if (o_split_ok(p, splits)) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
@@ -493,6 +510,7 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
         if (p.w_split && p.a_split) return launch_v3_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
     }
     return launch_v3_kernel<T, BM, BN, WM, WN, 0>(p, splits, stream);
+    }
 }
 
 // tile hints 71..74: phased K loop on 8 waves (2 x 4), one workgroup per CU
@@ -529,8 +547,8 @@ template <typename T>
 int colsum_rows_v23(const geo4d_conv_gemm_t& p) {
     const int sp = p.split_k > 1 ? p.split_k : 1;
     int rows = 0;
-    if (p.tile_hint >= 71 && p.tile_hint <= 74) rows = v3_native<T>(p, sp) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v3_fallback_hint(p.tile_hint));
-    else rows = v2_wave_rows(p.tile_hint);
+    if (p.tile_hint >= 71 && p.tile_hint <= 74) rows = v3_native<T>(p, sp) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v2_effective_hint<T>(v3_fallback_hint(p.tile_hint)));
+    else rows = v2_wave_rows(v2_effective_hint<T>(p.tile_hint));
     if (rows == 0 || !colsum_fast_ok(p, sp) || p.M % rows) return 0;
     return rows;
 }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __re
 
 // ---- GroupNorm pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU -----------------
 // st: (mean, rstd) per group of this frame's statistic (global memory or LDS)
-template <typename T, bool SPLIT>
+template <typename T, int SPLIT>      // SPLIT: 0 plain rows, 1 pre-split bf16 hi | lo (bf16x3 consumers), 2 pre-split f16 hi | lo (f16x2 consumers)
 __device__ __forceinline__ void gn_apply_body(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                               int HW, int C, int G, int R, const float* st, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, int act, int chunk, int f) {
@@ -229,13 +229,14 @@ __device__ __forceinline__ void gn_apply_body(const T* __restrict__ x, long ldx,
                     if (act == 1) o = silu_f(o);
                     e[j] = o;
                 }
-                if constexpr (SPLIT) store_split4(yb + (long)ru * ldy, cc, e);          // (ldy counts K elements of 4 bytes, like ldx)
+                if constexpr (SPLIT == 1) store_split4(yb + (long)ru * ldy, cc, e);          // (ldy counts K elements of 4 bytes, like ldx)
+                else if constexpr (SPLIT == 2) store_split4_f16(yb + (long)ru * ldy, cc, e);
                 else *(u32x4*)(yb + (long)ru * ldy + cc * EPC) = f32_to_chunk<T>(e);
             }
         }
     }
 }
-template <typename T, bool SPLIT>
+template <typename T, int SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                        int HW, int C, int G, int fps, int R,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = tid; c < cols; c += 256) Elem<T>::st(yr + c, __expf(xr[c] * scale - m) * inv);
 }
 
-template <typename T, bool SPLIT>
+template <typename T, int SPLIT>
 int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     constexpr int EPC = Elem<T>::EPC;
     int R = gn_rows_per_chunk(p.HW, p.F);
@@ -397,12 +398,12 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
             return GEO4D_EINVAL;
         }
     }
-    if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8))) { geo4d_set_error("groupnorm: split_out is the bf16x3 producer format: f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
+    if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8) || p.split_out > 2 || p.split_out < 0)) { geo4d_set_error("groupnorm: split_out (1 = bf16 hi | lo, 2 = f16 hi | lo) is a producer format for f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {
-        case GEO4D_F32: return p.split_out ? groupnorm_typed<float, true>(p, s) : groupnorm_typed<float, false>(p, s);
-        case GEO4D_BF16: return groupnorm_typed<bf16_t, false>(p, s);
-        default: return groupnorm_typed<f16_t, false>(p, s);
+        case GEO4D_F32: return p.split_out == 2 ? groupnorm_typed<float, 2>(p, s) : p.split_out ? groupnorm_typed<float, 1>(p, s) : groupnorm_typed<float, 0>(p, s);
+        case GEO4D_BF16: return groupnorm_typed<bf16_t, 0>(p, s);
+        default: return groupnorm_typed<f16_t, 0>(p, s);
     }
 }
 

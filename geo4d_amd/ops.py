@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, BF16X3, F16, F32, Attention, ConvGemm, GroupNorm
+from ._lib import BF16, BF16X3, F16, F16X2, F32, Attention, ConvGemm, GroupNorm
 from .precision import resolve as _resolve_precision
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
@@ -45,8 +45,21 @@ class SplitAct(torch.Tensor):
         return t.as_subclass(SplitAct)
 
 
-def new_split(rows, k, device):
-    return SplitAct.wrap(torch.empty((rows, 2 * k), device=device, dtype=torch.bfloat16))
+def new_split(rows, k, device, fmt="bf16"):
+    """`fmt`: "bf16" = the bf16x3 operand format; "f16" = the two-pass f16 format (dtype 4: [8 x f16 hi | 8 x f16 lo], consumed by
+    conv_gemm against a pack.split_f16 weight). The torch dtype of the buffer names the format."""
+    return SplitAct.wrap(torch.empty((rows, 2 * k), device=device, dtype=torch.float16 if fmt == "f16" else torch.bfloat16))
+
+
+def split_fmt(split_out):
+    """groupnorm(split_out=...) argument -> (ABI code, format name): False / None -> 0, True / "bf16" -> 1, "f16" -> 2."""
+    if not split_out:
+        return 0, None
+    if split_out is True or split_out == "bf16":
+        return 1, "bf16"
+    if split_out == "f16":
+        return 2, "f16"
+    raise ValueError(f"split_out={split_out!r}: False, True / 'bf16' or 'f16'")
 
 
 def act_k(x):
@@ -139,7 +152,7 @@ def _env_level(name, default):
 GN_FUSED_STATS = _env_level("GEO4D_GN_FUSED", 1)
 TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) of every shape autotuned in this process (tools/tune_gemm.py prints it)
 DEBUG_ABLATE = 0       # tools/gemm_bench.py --ablate only
-GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end)
+GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end, MFMA passes per product)
 ATTN_TIMELINE = None   # the same for the spatial self-attention launches (one key/value set) of ops.attention
 
 
@@ -222,7 +235,16 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     if isinstance(out, SplitAct) and batch == 1:
         _split_out_ok(out, M)
     a_split, w_split = is_split(a, w), is_split(w, a)
-    if isinstance(a, SplitAct) or isinstance(w, SplitAct):     # pre-split activations x pre-split weights (bf16 storage, 4 bytes per K element)
+    if isinstance(a, SplitAct) and a.dtype == torch.float16:
+        # two-pass f16 (dtype 4): a GroupNorm output in the f16 pre-split format x a pack.split_f16 weight (which carries its 1 / scale)
+        assert w.dtype == torch.float16 and hasattr(w, "_x2_alpha"), "an f16 SplitAct multiplies a pack.split_f16 weight"
+        assert not isinstance(out, SplitAct) and out.dtype == torch.float32 and not out_nchw, "the two-pass f16 GEMM writes plain f32 rows"
+        assert lda % 2 == 0 and ldw % 2 == 0 and a_bs % 2 == 0 and w_bs % 2 == 0
+        a_split = w_split = True
+        code = F16X2
+        alpha = alpha * w._x2_alpha
+        lda, a_bs, ldw, w_bs = lda // 2, a_bs // 2, ldw // 2, w_bs // 2
+    elif isinstance(a, SplitAct) or isinstance(w, SplitAct):     # pre-split activations x pre-split weights (bf16 storage, 4 bytes per K element)
         assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and lda % 2 == 0 and ldw % 2 == 0 and a_bs % 2 == 0 and w_bs % 2 == 0
         a_split = w_split = True
         code = BF16X3
@@ -275,7 +297,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
 
     if tile_hint == 0 and split_k == 0:
         key = f"{p.dtype}/{p.out_dtype}|{M}x{N}x{K}|c{Cin}|t{KT}{KH}{KW}s{stride}u{ups}|a{act}r{int(residual is not None)}n{int(out_nchw)}|b{batch}"
-        if code == BF16X3:
+        if code in (BF16X3, F16X2):
             key += f"|x{int(a_split)}{int(w_split)}" + ("o" if p.o_split else "")
         cfg = _tune_table().get(key)
         if cfg is None and code == BF16X3 and a_split and w_split:
@@ -286,6 +308,11 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
                 # the pre-split output has no split-K form (the reduce kernel writes plain f32): measure this launch on its own when
                 # that is allowed, else keep the tile and drop the split
                 cfg = None if (AUTOTUNE and not torch.cuda.is_current_stream_capturing()) else (cfg[0], 1)
+        if cfg is None and code == F16X2 and not (AUTOTUNE and not torch.cuda.is_current_stream_capturing()):
+            # no entry and no measuring now: the bf16x3 launch of the same shape is the same tile geometry and the same bytes
+            cfg = _tune_table().get("3" + key[1:])
+            if cfg is not None and cfg[0] < 22:
+                cfg = None                   # (the two-pass kernels exist on the second / third generation only: library default)
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
@@ -314,7 +341,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         e0.record()
         launch(tile_hint, split_k)
         e1.record()
-        GEMM_TIMELINE.append((2.0 * M * N * K * batch, e0, e1))
+        GEMM_TIMELINE.append((2.0 * M * N * K * batch, e0, e1, {BF16X3: 3, F16X2: 2}.get(code, 1)))    # (flops, events, MFMAs issued per product)
         return out
     launch(tile_hint, split_k)
     return out
@@ -390,7 +417,8 @@ _gn_ws = {}
 
 
 def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=False, out=None, split_out=False):
-    """`split_out` (f32 input of the bf16x3 mode): y is returned as a SplitAct, the pre-split A operand of the conv that follows."""
+    """`split_out` (f32 input of the bf16x3 mode): y is returned as a SplitAct, the pre-split A operand of the conv that follows -
+    True / "bf16": bf16 hi | lo (three-pass bf16x3 consumer); "f16": f16 hi | lo (two-pass f16 consumer, pack.split_f16 weights)."""
     lib = _lib.load()
     _dev(x, "x")
     assert not isinstance(x, SplitAct), "GroupNorm reads plain activations"
@@ -398,9 +426,10 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     assert x.shape[0] == F * HW, (x.shape, F, HW)
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
     if out is None:
-        out = new_split(F * HW, Cc, x.device) if split_out else torch.empty((F * HW, Cc), device=x.device, dtype=x.dtype)
-    split_out = isinstance(out, SplitAct)
+        out = new_split(F * HW, Cc, x.device, split_fmt(split_out)[1]) if split_out else torch.empty((F * HW, Cc), device=x.device, dtype=x.dtype)
+    split_out = (2 if out.dtype == torch.float16 else 1) if isinstance(out, SplitAct) else 0
     if split_out:
+        assert x.dtype == torch.float32, "the pre-split producer formats are written from f32 activations"
         _split_out_ok(out, F * HW)
     need = lib.geo4d_groupnorm_workspace(F, HW, groups, frames_per_stat)
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)

@@ -20,6 +20,35 @@ def split_bf16(w):
     return torch.stack([hi.reshape(n, k // 8, 8), lo.reshape(n, k // 8, 8)], dim=2).reshape(n, 2 * k).contiguous()
 
 
+def split_f16(w):
+    """[N, K] fp32 (K % 8 == 0) -> the pre-split weight of the two-pass f16 GEMM (include/geo4d_hip.h dtype 4): a float16 tensor
+    [N, 2K] holding, per 8 K-elements, [8 x hi | 8 x lo] with hi = f16(s w), lo = f16(s w - hi) and s a power of two that puts the
+    largest |w| at 2^13..2^14 (hi well inside the f16 range, lo of every weight that matters a NORMAL f16 number: hi + lo then carries
+    ~22 bits). The launch multiplies its accumulators by 1 / s (`_x2_alpha`, exact), before bias / residual."""
+    n, k = w.shape
+    assert k % 8 == 0
+    w = w.float()
+    amax = float(w.abs().max())
+    e = 0 if amax == 0.0 or not torch.isfinite(torch.tensor(amax)) else 13 - int(torch.floor(torch.log2(torch.tensor(amax))))
+    e = max(-24, min(24, e))
+    ws = w * (2.0 ** e)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    out = torch.stack([hi.reshape(n, k // 8, 8), lo.reshape(n, k // 8, 8)], dim=2).reshape(n, 2 * k).contiguous()
+    out._x2_alpha = 2.0 ** -e
+    return out
+
+
+def pack_conv2d_x2(w, dtype, cin_pad=None):
+    """nn.Conv2d weight -> the two-pass f16 operand ([Cout, 2 * KH*KW*Cin_pad] float16 + `_x2_alpha`), same K order as pack_conv2d."""
+    co, ci, kh, kw = w.shape
+    cp = cin_pad or pad_to(ci, k_align(dtype))
+    w = w.permute(0, 2, 3, 1)
+    if cp != ci:
+        w = torch.nn.functional.pad(w, (0, cp - ci))
+    return split_f16(w.reshape(co, kh * kw * cp))
+
+
 def cast(w, dtype):
     """2-D K-major weight -> operand format of the compute mode (``dtype``: Precision, name or torch dtype)."""
     prec = resolve(dtype)

@@ -7,8 +7,20 @@ name       activation storage   GEMM / attention arithmetic   point-map parity v
 ``f16``    float16              f16 MFMA, fp32 accumulate     ~2.5e-3
 ``bf16x3`` float32              3 bf16 MFMAs per product on   < 1e-4: meets the bar at ~1/3 of the bf16 MFMA rate
                                 a hi/lo split of each operand
+``bf16x3m`` float32             bf16x3, except the long-K     ~2e-4 (measured at BASELINE size over 50 steps:
+                                3x3 convolutions (U-Net       tests/test_fullsize_gpu.py): the convolutions that are
+                                ResBlocks, VAE ResnetBlocks): MFMA-bound issue 2 MFMAs per product instead of 3
+                                two f16 MFMAs per product on
+                                an f16 activation x an
+                                f16 hi + lo weight
 ``f32``    float32              v_mfma_f32_32x32x2_f32        ~2e-6 (exact f32; 1/16 of the bf16 MFMA rate)
 =========  ===================  ============================  ==========================================================
+
+``bf16x3m`` (round 5, "mixed passes"): the error budget of the 1e-3 bar is spent where it buys MFMA time. Rounding ONLY the
+A operand of the 3x3 convolutions to f16 (weights kept to ~22 bits as f16 hi + lo) moves the point map by 1.3e-4 .. 2.9e-4
+on the simulated window (tests/precision_sim.py: 3 / 10 DDIM steps), an order of magnitude less than rounding every GEMM
+input (1.2e-3), because these 44 + 3 x 24 launches are 33 % of the FLOPs but a small share of the network's rounding points;
+the same rounding on the projections alone costs 5.8e-4, on everything 8.3e-4 - so only the convolutions take it.
 
 Why ``bf16x3`` exists: rounding ONLY the weights of the U-Net to f16 (activations exact) already costs 1.4e-3 on the point
 map, rounding only the GEMM inputs another 1.2e-3 (tests/precision_sim.py, tests/test_precision_floor.py) — no single pass
@@ -23,10 +35,10 @@ import torch
 
 
 class Precision:
-    __slots__ = ("name", "storage", "x3")
+    __slots__ = ("name", "storage", "x3", "two_pass_conv")
 
-    def __init__(self, name, storage, x3=False):
-        self.name, self.storage, self.x3 = name, storage, x3
+    def __init__(self, name, storage, x3=False, two_pass_conv=False):
+        self.name, self.storage, self.x3, self.two_pass_conv = name, storage, x3, two_pass_conv
 
     def __repr__(self):
         return f"Precision({self.name})"
@@ -43,9 +55,10 @@ BF16 = Precision("bf16", torch.bfloat16)
 F16 = Precision("f16", torch.float16)
 F32 = Precision("f32", torch.float32)
 BF16X3 = Precision("bf16x3", torch.float32, x3=True)
+BF16X3M = Precision("bf16x3m", torch.float32, x3=True, two_pass_conv=True)
 
 _BY_NAME = {"bf16": BF16, "bfloat16": BF16, "f16": F16, "fp16": F16, "float16": F16, "f32": F32, "fp32": F32, "float32": F32,
-            "bf16x3": BF16X3, "bf16_3x": BF16X3, "3xbf16": BF16X3}
+            "bf16x3": BF16X3, "bf16_3x": BF16X3, "3xbf16": BF16X3, "bf16x3m": BF16X3M, "mixed": BF16X3M}
 _BY_TORCH = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}
 
 
@@ -65,5 +78,5 @@ def resolve(d=None):
         d = os.environ.get("GEO4D_DTYPE", "bf16")
     p = _coerce(d)
     if p is None:
-        raise ValueError(f"geo4d_amd: unknown compute dtype {d!r} (bf16, f16, bf16x3, f32)")
+        raise ValueError(f"geo4d_amd: unknown compute dtype {d!r} (bf16, f16, bf16x3, bf16x3m, f32)")
     return p

@@ -299,8 +299,11 @@ class UNetModel(ParamTree):
                 e["cpad"] = pack.pad_to(L.cin, ops.k_align(dt))
             elif L.kind == "res":
                 e["gn1"], e["gn2"] = norm(p + ".in_layers.0"), norm(p + ".out_layers.0")
-                e["w1"], e["b1"] = pack.pack_conv2d(sd[p + ".in_layers.2.weight"], dt), f32(p + ".in_layers.2.bias")
-                e["w2"], e["b2"] = pack.pack_conv2d(sd[p + ".out_layers.3.weight"], dt), f32(p + ".out_layers.3.bias")
+                # bf16x3m: the ResBlocks' two 3x3 convolutions take the two-pass f16 form (precision.py; their GroupNorms then write f16 hi | lo)
+                pk = pack.pack_conv2d_x2 if (dt.two_pass_conv and self.presplit) else pack.pack_conv2d
+                e["x2"] = pk is pack.pack_conv2d_x2
+                e["w1"], e["b1"] = pk(sd[p + ".in_layers.2.weight"], dt), f32(p + ".in_layers.2.bias")
+                e["w2"], e["b2"] = pk(sd[p + ".out_layers.3.weight"], dt), f32(p + ".out_layers.3.bias")
                 emb_w.append(sd[p + ".emb_layers.1.weight"].float()); emb_b.append(sd[p + ".emb_layers.1.bias"].float())
                 e["emb"] = (off, off + L.cout); off += L.cout
                 if L.cin != L.cout:
@@ -401,11 +404,12 @@ class UNetModel(ParamTree):
     def _res(self, e, L, h, emb_all, B, T, H, W):
         F_, HW = B * T, H * W
         sp = self.presplit
-        a = ops.groupnorm(h, *e["gn1"], F=F_, HW=HW, eps=1e-5, silu=True, split_out=sp)
+        sp3 = "f16" if e.get("x2") else sp           # operand format of the two 3x3 convolutions
+        a = ops.groupnorm(h, *e["gn1"], F=F_, HW=HW, eps=1e-5, silu=True, split_out=sp3)
         lo, hi = e["emb"]
         h1, _, _ = ops.conv2d(a, e["w1"], e["b1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, rowbias=emb_all[:, lo:hi],
                               rowbias_div=T * HW, gn_stats=True)      # gn_stats: the epilogue sums the next GroupNorm's statistics
-        a = ops.groupnorm(h1, *e["gn2"], F=F_, HW=HW, eps=1e-5, silu=True, split_out=sp)
+        a = ops.groupnorm(h1, *e["gn2"], F=F_, HW=HW, eps=1e-5, silu=True, split_out=sp3)
         skip = ops.linear(h, *e["skip"]) if "skip" in e else h
         h2, _, _ = ops.conv2d(a, e["w2"], e["b2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True)
         if "tc" in e:

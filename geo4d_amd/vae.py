@@ -163,16 +163,19 @@ class AutoencoderKL(ParamTree):
         P["cpad"] = ka
         P["conv_in"] = (pack.pack_conv2d(sd["decoder.conv_in.weight"], dt, cin_pad=ka), f32("decoder.conv_in.bias"))
 
-        def resnet(p):
+        def resnet(p, two_pass=False):
+            # bf16x3m: the DECODER's ResnetBlock convolutions (decoder.* and decoder_adaptor.*) take the two-pass f16 form (precision.py)
+            pk = pack.pack_conv2d_x2 if (two_pass and dt.two_pass_conv and self.presplit) else pack.pack_conv2d
             e = dict(gn1=norm(p + ".norm1"), gn2=norm(p + ".norm2"),
-                     c1=(pack.pack_conv2d(sd[p + ".conv1.weight"], dt), f32(p + ".conv1.bias")),
-                     c2=(pack.pack_conv2d(sd[p + ".conv2.weight"], dt), f32(p + ".conv2.bias")))
+                     c1=(pk(sd[p + ".conv1.weight"], dt), f32(p + ".conv1.bias")),
+                     c2=(pk(sd[p + ".conv2.weight"], dt), f32(p + ".conv2.bias")))
+            e["x2"] = pk is pack.pack_conv2d_x2
             if (p + ".nin_shortcut.weight") in sd:
                 e["nin"] = (pack.pack_linear(sd[p + ".nin_shortcut.weight"], dt), f32(p + ".nin_shortcut.bias"))
             return e
         for kind, p, ci, co in self.plan:
             if kind == "res":
-                P[p] = resnet(p)
+                P[p] = resnet(p, two_pass=True)
             elif kind == "attn":
                 P[p] = dict(norm=norm(p + ".norm"),
                             qk=(pack.pack_linear(torch.cat([sd[p + ".q.weight"], sd[p + ".k.weight"]], 0), dt),
@@ -187,7 +190,7 @@ class AutoencoderKL(ParamTree):
                           sd["decoder.conv_out.bias"].mean().reshape(1).float().contiguous())
         if self.adaptorconfig is not None:
             nb = self.adaptorconfig["num_res_blocks"] + 1
-            P["adaptor"] = [resnet(f"decoder_adaptor.up.0.block.{b}") for b in range(nb)]
+            P["adaptor"] = [resnet(f"decoder_adaptor.up.0.block.{b}", two_pass=True) for b in range(nb)]
             P["adaptor_head"] = (norm("decoder_adaptor.norm_out"), pack.pack_conv2d(sd["decoder_adaptor.conv_out.weight"], dt),
                                  f32("decoder_adaptor.conv_out.bias"))
         # ---- encoder (ae_modules.py:537-580) + quant_conv folded into conv_out -------------------------------------
@@ -234,7 +237,7 @@ class AutoencoderKL(ParamTree):
         return bool(self.compute_dtype.x3) and PRESPLIT
 
     def _resnet(self, e, x, F_, H, W):
-        sp = self.presplit
+        sp = "f16" if e.get("x2") else self.presplit
         a = ops.groupnorm(x, *e["gn1"], F=F_, HW=H * W, eps=1e-6, silu=True, split_out=sp)
         h, _, _ = ops.conv2d(a, *e["c1"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True)
         a = ops.groupnorm(h, *e["gn2"], F=F_, HW=H * W, eps=1e-6, silu=True, split_out=sp)

@@ -13,6 +13,10 @@
  *     3 = bf16x3 (conv_gemm / attention only): operands are f32 in memory (4 bytes per element, `ld*` in elements) and
  *     are multiplied as bf16 hi + bf16 lo with three bf16 MFMAs per product (~16 mantissa bits at 1/3 of the bf16
  *     rate instead of 1/16 for f32 MFMA) — the mode that meets the 1e-3 parity bar; every other entry point takes 0 for it;
+ *     4 = f16x2 (conv_gemm only, round 5): both operands PRE-SPLIT as [8 x f16 hi | 8 x f16 lo] per 8 K-elements (the bf16x3
+ *     pre-split layout with f16 halves; 4 bytes per element, `ld*` in elements); the product is a_hi.w_hi + a_hi.w_lo — TWO f16
+ *     MFMAs: the activation carries 11 mantissa bits, the weight ~22. Used for the long-K 3x3 convolutions of the "bf16x3m" mode
+ *     (tests/precision_sim.py: the point map stays < 3e-4 where a full f16 pass costs 2e-3); tile hints 0 or >= 22, f32 rows out;
  *   - every row pitch / base pointer must be 16-byte aligned (kernels move 16-byte chunks);
  *   - return 0 on success, negative errno-style code otherwise (-22 EINVAL, -95 ENOTSUP, -5 EIO = HIP launch
  *     error); geo4d_last_error() returns a thread-local message. Kernels never abort().
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GEO4D_ABI_VERSION 6
+#define GEO4D_ABI_VERSION 7
 
 /* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
  * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
@@ -72,8 +76,9 @@ typedef struct geo4d_conv_gemm_t {
     int debug_ablate;    /* 0 in production. 2 (tests only, tile hints >= 22): launch 3 persistent workgroups whatever the problem size,
                             so that small test shapes walk the persistent tile loop */
     float alpha;
-    int a_split, w_split;/* dtype 3 (bf16x3) only: the operand is stored PRE-SPLIT, per 8 K-elements
-                            [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32 */
+    int a_split, w_split;/* dtype 3 (bf16x3): the operand is stored PRE-SPLIT, per 8 K-elements
+                            [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32; dtype 4 (f16x2): both must
+                            be set (f16 halves: pack.py split_f16 for weights, geo4d_groupnorm_t.split_out = 2 for activations) */
     int o_split;         /* dtype 3 (bf16x3), a_split and w_split set, out_dtype F32: O is written in the pre-split operand
                             format ([8 x bf16 hi | 8 x bf16 lo] per 8 output columns; ldo / o_bs still count columns) - the producer
                             side of a_split (GEGLU -> FF-out chain; q | k and V^T of the spatial attention, geo4d_attention_t.qkv_split).
@@ -104,8 +109,9 @@ typedef struct geo4d_groupnorm_t {
     float eps;
     const float* colsum; /* optional: [F*HW/colsum_rows][C][2] column sums written by the producing geo4d_conv_gemm (gn_colsum); when
                             given the pass over x that computes the statistics is skipped */
-    int split_out;       /* bf16x3 producers (dtype F32 only, C % 8 == 0): y is written in the PRE-SPLIT operand format of
-                            geo4d_conv_gemm_t.a_split - per 8 channels [8 x bf16 hi | 8 x bf16 lo]; ldy still counts channels */
+    int split_out;       /* producers of GEMM operands (dtype F32 only, C % 8 == 0): y is written in the PRE-SPLIT operand format of
+                            geo4d_conv_gemm_t.a_split - 1: per 8 channels [8 x bf16 hi | 8 x bf16 lo] (bf16x3 consumers); 2: [8 x f16 hi |
+                            8 x f16 lo], values clamped to the f16 range (f16x2 consumers, dtype 4); ldy still counts channels */
     int colsum_rows;     /* rows per `colsum` entry (what geo4d_conv_gemm_colsum_rows returned for the producing launch); 0 = 32;
                             (frames_per_stat x HW) % colsum_rows == 0 */
 } geo4d_groupnorm_t;

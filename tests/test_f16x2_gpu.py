@@ -1,0 +1,172 @@
+"""The two-pass f16 GEMM of the bf16x3m mode (include/geo4d_hip.h dtype 4, round 5): pre-split [8 x f16 hi | 8 x f16 lo] operands,
+product = a_hi.w_hi + a_hi.w_lo on the second- / third-generation tiles, and its producer (GroupNorm with split_out = "f16").
+
+What is checked is the ARITHMETIC THE MODE CLAIMS, not a loose tolerance: the reference is PyTorch fp64 math on exactly the operands the
+kernel multiplies - the activation rounded to f16, the weight as (f16 hi + f16 lo) / scale - so the only difference left is the fp32
+accumulation order (1e-5 relative on the output norm); a kernel that dropped the lo pass, read the wrong half, or mis-scaled would be
+off by 1e-4 .. 1 there. Every case also runs on three persistent workgroups (`debug_ablate = 2`: the tile stream crosses tile
+boundaries on small shapes), and the third-generation tiles are compared bit for bit with a second-generation tile (same summation
+order by construction)."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from test_gemm_v2_gpu import both_grids, rel, rnd
+
+pytestmark = pytest.mark.gpu
+
+V2_TILES = [22, 23, 25, 27, 28]
+V3_TILES = [71, 72, 73, 74]
+
+
+def split_f16_act(x):
+    """Host twin of store_split4_f16 (common.h): f32 [M, K] -> float16 [M, 2K], per 8 elements [8 x hi | 8 x lo]."""
+    from geo4d_amd import ops
+    m, k = x.shape
+    c = x.float().clamp(-65504.0, 65504.0)
+    hi = c.to(torch.float16)
+    lo = (c - hi.float()).to(torch.float16)
+    return ops.SplitAct.wrap(torch.stack([hi.reshape(m, k // 8, 8), lo.reshape(m, k // 8, 8)], dim=2).reshape(m, 2 * k).contiguous())
+
+
+def weight_seen(wp):
+    """The weight values a pack.split_f16 operand represents: (hi + lo) * alpha, fp64, [N, K]."""
+    n, k2 = wp.shape
+    g = wp.reshape(n, k2 // 16, 2, 8).double()
+    return ((g[:, :, 0] + g[:, :, 1]).reshape(n, k2 // 2)) * wp._x2_alpha
+
+
+def a_seen(x):
+    return x.float().clamp(-65504.0, 65504.0).to(torch.float16).double()
+
+
+def close(name, got, ref, tol=1e-5):
+    e = rel(got.double(), ref.double())
+    assert torch.isfinite(got).all() and e < tol, f"{name}: rel_l2 {e:.3e} (tol {tol:.0e})"
+
+
+def test_pack_split_f16_represents_the_weight_to_22_bits(dev):
+    from geo4d_amd import pack
+    for scale in (1e-4, 0.03, 1.0, 300.0):
+        w = rnd((96, 256), dev, 1, scale)
+        wp = pack.split_f16(w)
+        assert wp.dtype == torch.float16 and wp.shape == (96, 512) and torch.isfinite(wp.float()).all()
+        e = rel(weight_seen(wp), w.double())
+        assert e < 2e-6, f"scale {scale}: hi + lo represents w to {e:.2e}"
+        hi_only = wp.reshape(96, 32, 2, 8)[:, :, 0].reshape(96, 256).double() * wp._x2_alpha
+        assert rel(hi_only, w.double()) > 1e-4          # (the lo half is doing the work)
+
+
+@pytest.mark.parametrize("tile", V2_TILES + V3_TILES)
+def test_linear_bias_residual_ragged(dev, tile):
+    from geo4d_amd import ops, pack
+    M, K, N = 1000, 512, 456
+    x, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.05)
+    b, r = rnd((N,), dev, 3), rnd((M, N), dev, 4)
+    wp, xs = pack.split_f16(w), split_f16_act(x)
+    out = both_grids(lambda: ops.linear(xs, wp, b, residual=r, tile_hint=tile))
+    assert out.dtype == torch.float32 and out.shape == (M, N)
+    close(f"linear tile{tile}", out, a_seen(x) @ weight_seen(wp).t() + b.double() + r.double())
+    if tile >= 71:
+        assert torch.equal(out, ops.linear(xs, wp, b, residual=r, tile_hint=25)), f"tile {tile} differs from the second generation"
+    # the error the mode accepts: the activation is an f16, nothing else
+    full = x.double() @ w.double().t() + b.double() + r.double()
+    e = rel(out.double(), full)
+    assert 1e-5 < e < 6e-4, f"distance to exact math {e:.2e}: expected the f16 rounding of the activation (~2e-4), not more, not less"
+
+
+@pytest.mark.parametrize("tile", V3_TILES + [23, 25])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv3x3_rowbias_residual_split_k(dev, tile, stride):
+    from geo4d_amd import ops, pack
+    F, H, W, Ci, Co = 5, 12, 9, 256, 200
+    x_nchw = rnd((F, Ci, H, W), dev, 10)
+    wc, bc = rnd((Co, Ci, 3, 3), dev, 11, 0.03), rnd((Co,), dev, 12)
+    emb = rnd((F, Co), dev, 13)
+    xt = x_nchw.permute(0, 2, 3, 1).reshape(F * H * W, Ci).contiguous()
+    wp = pack.pack_conv2d_x2(wc, "bf16x3m")
+    ws = weight_seen(wp).reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)                    # back to [Co, Ci, 3, 3]
+    xa = a_seen(xt).reshape(F, H, W, Ci).permute(0, 3, 1, 2)
+    ref = TF.conv2d(xa, ws, bc.double(), stride=stride, padding=1) + emb.double()[:, :, None, None]
+    Ho, Wo = ref.shape[-2:]
+    r = rnd((F * Ho * Wo, Co), dev, 14)
+    ref = ref.permute(0, 2, 3, 1).reshape(F * Ho * Wo, Co) + r.double()
+    xs = split_f16_act(xt)
+    for split in (1, 2, 3):
+        def run(t):
+            return ops.conv2d(xs, wp, bc, F=F, Hin=H, Win=W, KH=3, KW=3, stride=stride, pad=1, rowbias=emb, rowbias_div=Ho * Wo, residual=r,
+                              tile_hint=t, split_k=split)[0]
+        o = both_grids(lambda: run(tile))
+        close(f"conv tile{tile} stride{stride} split{split}", o, ref)
+        if tile >= 71:
+            assert torch.equal(o, run(25)), f"conv tile{tile} split{split}: differs from the second generation"
+
+
+def test_default_tile_and_fallbacks(dev):
+    """tile_hint 0 (the library picks), an odd K-slab count on a third-generation hint (runs on its second-generation twin), and what
+    the C ABI must refuse: first-generation hints, raw (un-split) operands, a pre-split output."""
+    from geo4d_amd import ops, pack
+    M, N = 640, 128
+    for K in (160, 320, 1024):
+        x, w, b = rnd((M, K), dev, 30), rnd((N, K), dev, 31, 0.1), rnd((N,), dev, 32)
+        wp, xs = pack.split_f16(w), split_f16_act(x)
+        ref = a_seen(x) @ weight_seen(wp).t() + b.double()
+        for tile in (0, 72, 74):
+            close(f"K{K} tile{tile}", ops.linear(xs, wp, b, tile_hint=tile, split_k=1 if tile else 0), ref)
+    with pytest.raises(RuntimeError):
+        ops.linear(xs, wp, b, tile_hint=1, split_k=1)
+    with pytest.raises(AssertionError):
+        ops.linear(xs, wp, b, split_out=True)                       # the two-pass GEMM writes plain f32 rows
+    with pytest.raises(AssertionError):
+        ops.linear(xs, pack.split_bf16(w), b)                       # an f16 activation needs an f16-split weight
+
+
+@pytest.mark.parametrize("fps", [1, 4])
+def test_groupnorm_f16_split_output_and_fused_statistics(dev, fps):
+    """GroupNorm(+SiLU) writing the f16 pre-split format == the host split of the plain-f32 GroupNorm of the same input; then the whole
+    chain the networks run: GroupNorm -> two-pass conv (emits the next GroupNorm's column sums) -> GroupNorm from those sums."""
+    from geo4d_amd import ops, pack
+    F, H, W, C = 4, 10, 16, 320
+    x = rnd((F * H * W, C), dev, 40) * 3.0 + 0.5
+    gamma, beta = rnd((C,), dev, 41) + 1.0, rnd((C,), dev, 42)
+    plain = ops.groupnorm(x, gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True)
+    sp = ops.groupnorm(x, gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True, split_out="f16")
+    assert isinstance(sp, ops.SplitAct) and sp.dtype == torch.float16 and sp.shape == (F * H * W, 2 * C)
+    assert torch.equal(sp.view(torch.int16), split_f16_act(plain).view(torch.int16)), "f16 split output differs from split(plain GroupNorm)"
+    wc, bc = rnd((C, C, 3, 3), dev, 43, 0.02), rnd((C,), dev, 44)
+    wp = pack.pack_conv2d_x2(wc, "bf16x3m")
+    old = ops.GN_FUSED_STATS
+    try:
+        outs = {}
+        for fused in (0, 1):
+            ops.GN_FUSED_STATS = fused
+            h, _, _ = ops.conv2d(sp, wp, bc, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True, tile_hint=72, split_k=1)
+            assert (getattr(h, "_gn_colsum", None) is not None) == bool(fused)
+            outs[fused] = (h, ops.groupnorm(h, gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True))
+    finally:
+        ops.GN_FUSED_STATS = old
+    assert torch.equal(outs[0][0], outs[1][0])
+    close("GroupNorm from the two-pass conv's column sums", outs[1][1], outs[0][1], tol=2e-6)
+    ws = weight_seen(wp).reshape(C, 3, 3, C).permute(0, 3, 1, 2)
+    ref = TF.conv2d(a_seen(plain).reshape(F, H, W, C).permute(0, 3, 1, 2), ws, bc.double(), padding=1).permute(0, 2, 3, 1).reshape(F * H * W, C)
+    close("GroupNorm -> two-pass conv", outs[0][0], ref)
+
+
+def test_full_chip_stream_is_deterministic(dev):
+    """The U-Net's largest 3x3 convolution (M = 40960, K = 2880, N = 320) on every tile that can serve it: five launches bit-identical,
+    third == second generation bit for bit."""
+    from geo4d_amd import ops, pack
+    F, H, W, C = 16, 40, 64, 320
+    xt = rnd((F * H * W, C), dev, 50)
+    wc, bc = rnd((C, C, 3, 3), dev, 51, 0.02), rnd((C,), dev, 52)
+    wp, xs = pack.pack_conv2d_x2(wc, "bf16x3m"), split_f16_act(xt)
+    base = None
+    for tile in (23, 71, 72, 74):
+        outs = [ops.conv2d(xs, wp, bc, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, tile_hint=tile, split_k=1)[0].clone() for _ in range(5)]
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), f"tile {tile}: launches differ"
+        base = outs[0] if base is None else base
+        assert torch.equal(outs[0], base), f"tile {tile} differs from tile 23"
+    ws = weight_seen(wp).reshape(C, 3, 3, C).permute(0, 3, 1, 2)
+    sub = slice(0, 2)                                                     # two frames of the fp64 reference are enough
+    ref = TF.conv2d(a_seen(xt).reshape(F, H, W, C)[sub].permute(0, 3, 1, 2), ws, bc.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, C)
+    close("L0 conv3x3", base[: 2 * H * W], ref)

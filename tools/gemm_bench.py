@@ -50,7 +50,7 @@ SHAPES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="bf16", help="bf16 | f16 | f32 | bf16x3 | f16x2 (two-pass f16 of the bf16x3m mode: 3x3 conv rows, pre-split operands)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--filter", default="")
     ap.add_argument("--tile", type=int, default=0)
@@ -66,11 +66,18 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="bf16x3 only: 1 = skip the in-register operand split (wrong numbers; measures its cost)")
     args = ap.parse_args()
     ops.DEBUG_ABLATE = args.ablate
+    x2 = args.dtype == "f16x2"       # the two-pass f16 GEMM of the bf16x3m mode (dtype 4): conv3x3 rows only, pre-split operands
     x3 = args.dtype == "bf16x3"
-    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "bf16x3": torch.float32}[args.dtype]
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "bf16x3": torch.float32, "f16x2": torch.float32}[args.dtype]
     from geo4d_amd import pack
-    wcast = (lambda w: pack.split_bf16(w)) if x3 else (lambda w: w.to(dt))
+    wcast = (lambda w: pack.split_bf16(w)) if x3 else (lambda w: pack.split_f16(w)) if x2 else (lambda w: w.to(dt))
     acast = (lambda a: ops.SplitAct.wrap(pack.split_bf16(a))) if (x3 and args.presplit) else (lambda a: a)
+    if x2:
+        def acast(a):
+            hi = a.to(torch.float16)
+            lo = (a - hi.float()).to(torch.float16)
+            m, k = a.shape
+            return ops.SplitAct.wrap(torch.stack([hi.reshape(m, k // 8, 8), lo.reshape(m, k // 8, 8)], dim=2).reshape(m, 2 * k).contiguous())
     dev = torch.device("cuda:0")
     if args.zeros:
         torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "generator"})
@@ -78,6 +85,8 @@ def main():
     print(f"{'shape':34s} {'M':>8s} {'N':>6s} {'K':>6s} {'us':>9s} {'TF/s':>8s}  x count -> ms/forward")
     for name, kind, geo, N, Cin, cnt in SHAPES:
         if args.filter and args.filter not in name:
+            continue
+        if x2 and kind != "c3":
             continue
         if kind == "c3":
             F_, H, W = geo
