@@ -204,6 +204,27 @@ def synthetic_scene_maps(slices, T, H, W, dev):
     return maps, traj
 
 
+def synthetic_scene_truth_check(scene, N, H, W, dev):
+    """What the optimised scene says against the synthetic scene it was given (synthetic_scene_maps): depth of every global frame i is
+    z_i(u, v) = 0.5 + 0.1 sin(2 pi (u + 8 i) / W) cos(pi v / H) and the camera slides 0.01 per frame along x. The alignment is free up to
+    one similarity, so: depth maps after ONE global median scale (relative L2), and the camera track's consecutive steps (equal length,
+    collinear). Size-independent properties of the full-size run; the parity of the objective itself is tests/test_align_gpu.py::
+    test_clip_alignment_full_size_vs_oracle."""
+    import math
+    v, u = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32) - H / 2, torch.arange(W, device=dev, dtype=torch.float32) - W / 2, indexing="ij")
+    i = torch.arange(N, device=dev, dtype=torch.float32).view(N, 1, 1)
+    gt = 0.5 + 0.1 * torch.sin(2 * math.pi * (u + W / 2 + 8.0 * i) / W) * torch.cos(math.pi * v / H)
+    est = scene.get_depthmaps().float()
+    s = (gt / est.clamp_min(1e-9)).flatten().median()
+    depth_err = float(((s * est - gt).double().norm() / gt.double().norm()))
+    c = scene.get_im_poses_matrix()[:, :3, 3].double()
+    d = c[1:] - c[:-1]
+    step = d.norm(dim=1)
+    cosang = (d[1:] * d[:-1]).sum(1) / (step[1:] * step[:-1]).clamp_min(1e-30)
+    return {"depth_rel_l2_after_global_scale": depth_err, "track_step_spread": float(step.std() / step.mean()),
+            "track_min_cos_between_steps": float(cosang.min()), "track_step_over_depth_scale": float(step.mean() * s)}
+
+
 def clip_mode(args, model, pvae, dev, rank, world, clip_kw=None, align_fn=None):
     """`--clip-frames N`: ONE synthetic N-frame clip end to end, the way the reference's evaluation entry times it
     (scripts/evaluation/infer_geo4d.py:437-463 window loop, :503-511 alignment): sliding 16-frame windows (stride 4, tail window
@@ -253,10 +274,14 @@ def clip_mode(args, model, pvae, dev, rank, world, clip_kw=None, align_fn=None):
     if rank != 0:
         return None
     depth_ok = bool(torch.isfinite(scene.get_depthmaps()).all()) and bool(torch.isfinite(scene.get_im_poses_matrix()).all())
+    truth = None
+    if not args.clip_align_on_noise and align_fn is None:
+        truth = synthetic_scene_truth_check(scene, N, H, W, dev)
     nwin = len(window_slices(N, 4, 16))
     dn, init_s, opt_s, tot = (float(v) for v in ph)
     return {
-        "metric": f"end-to-end clip frames/sec ({N}x{H}x{W} clip -> {nwin} windows of 16, {args.ddim_steps}-step DDIM + decode + multi-window alignment)",
+        "metric": f"end-to-end clip frames/sec ({N}x{H}x{W} clip -> {nwin} windows of 16, {args.ddim_steps}-step DDIM + decode + multi-window alignment"
+                  + (" of the decoded noise)" if args.clip_align_on_noise else "; alignment phases on a synthetic scene of the same shapes)"),
         "value": N / tot, "unit": "frames/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * tot, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic (seeded uniform video, N(0,1) context, random-init weights for the denoise / decode phases; the alignment phases run on "
@@ -264,13 +289,16 @@ def clip_mode(args, model, pvae, dev, rank, world, clip_kw=None, align_fn=None):
                    "noise between the phases (untimed): a curved wall in front of a sliding camera, bench.synthetic_scene_maps") + ")",
         "config": {"workload": f"ONE {N}-frame {H}x{W} clip: {nwin} sliding windows (stride 4, tail appended) x (VAE encode + {args.ddim_steps}-step DDIM + 4-modality "
                                f"decode + Plücker cameras), all-gather, post_optimization ({args.align_iters} Adam iterations, both late terms); BASELINE.json "
-                               f"configs[{2 if N == 64 else 3 if N == 128 else '2/3-style'}]{' on one GPU' if world == 1 else ''}",
+                               f"configs[{2 if N == 64 else 3 if N == 128 else '2/3-style'}]{' on one GPU' if world == 1 else ''}"
+                               + (" at the Sintel evaluation size (lvdm/data/eval_dataset_geo4d.py:15)" if (H, W) == (256, 576) else ""),
                    "windows": nwin, "windows_per_rank_max": (nwin + world - 1) // world,
                    "parallelism": f"window-dp{world}" + (" + frame-sharded VAE decode + RCCL all-gather + alignment sharded by window blocks (one all-reduce per iteration)" if world > 1 else ""),
                    "hipgraph": not args.no_graph},
         "phase_seconds": {"denoise_decode_gather": dn, "alignment_init": init_s, f"alignment_{args.align_iters}_iterations": opt_s, "total": tot},
         "denoised_frames_per_sec": 16 * nwin / dn,          # the headline metric's unit, inside the clip (windows overlap: 16 x windows frames are denoised)
         "alignment_outputs_finite": depth_ok,
+        # the synthetic scene has a known answer: the aligned depth maps / camera track against it (similarity-invariant measures)
+        "alignment_vs_scene_truth": truth,
     }
 
 
@@ -349,6 +377,9 @@ def main():
     ap.add_argument("--clip-align-on-noise", action="store_true", help="--clip-frames: run the alignment on the decoded noise of the random-init network instead of "
                     "the synthetic scene (its logs / medians go non-finite)")
     ap.add_argument("--align-iters", type=int, default=500, help="--clip-frames: Adam iterations of the global alignment (postprocess.n_iter of the shipped config)")
+    ap.add_argument("--no-clip-leg", action="store_true", help="skip the end-to-end clip leg the default run appends under `clip_mode` (ONE 64-frame clip: 14 sliding "
+                    "windows + decode + cameras + multi-window alignment, strong-scaled over the ranks; ~45 s on one GPU)")
+    ap.add_argument("--clip-leg-frames", type=int, default=64, help="frames of that clip (64 = BASELINE configs[2]'s window structure, 128 = configs[3])")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -537,6 +568,20 @@ def main():
             res["fast_mode"] = {"dtype": "bf16", "value": T * B * fsteps * world / fdt, "unit": "frames/s", "ms_per_step": 1e3 * fdt / fsteps,
                                 "steps": fsteps, "split_ms_per_step": {"ddim_denoise": fsplit[0] / fsteps, "vae_decode_4_modalities": fsplit[1] / fsteps},
                                 "parity": "point map ~2e-2 rel L2 vs the fp32 reference (tests/test_parity_gpu.py): NOT the 1e-3 bar, hence not the headline"}
+    if not args.no_clip_leg and B == 1 and T == 16:
+        # north_star's strong-scaling sentence in the SAME record: one clip, windows round-robin over the ranks, frame-sharded decode, all-gather,
+        # sharded alignment (clip_mode above). A failure here must not cost the headline: it is reported under the key instead.
+        import copy
+        a2 = copy.copy(args)
+        a2.clip_frames = args.clip_leg_frames
+        try:
+            cm = clip_mode(a2, model, pvae, dev, rank, world)
+        except Exception as e:       # noqa: BLE001 - whatever it is, the line still goes out
+            cm = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            res["clip_mode"] = cm if "error" in cm else {k: cm[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "scaling", "phase_seconds",
+                                                                           "denoised_frames_per_sec", "alignment_outputs_finite", "alignment_vs_scene_truth", "data")} | {
+                "windows": cm["config"]["windows"], "windows_per_rank_max": cm["config"]["windows_per_rank_max"], "parallelism": cm["config"]["parallelism"]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, pvae, args.ddim_steps, T, h, w)

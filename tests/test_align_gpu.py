@@ -443,3 +443,63 @@ def test_fused_parameter_chain_rule_equals_autograd(fix, dev, shared):
     assert float(g_h["im_poses"][2, 5]) == 0.0 and float(g_h["pw_poses"][1, 4]) == 0.0
     loss2, g2 = a.loss_and_grads()
     assert torch.equal(loss_h, loss2) and all(torch.equal(g_h[k], g2[k]) for k in g_h)
+
+
+def _oracle_view(scene, requires_grad=True):
+    """(P, data, kw) of oracle.align.alignment_loss for a GroupAligner's CURRENT parameters and inputs, on the CPU."""
+    P = {k: v.detach().cpu().clone().requires_grad_(requires_grad) for k, v in scene.P.items()}
+    G_, S = scene.G, scene.S
+    data = dict(pred=scene.pred.cpu(), conf=scene.conf.cpu(), H=scene.H, W=scene.W, e_all=scene.e_all.cpu())
+    if scene.invdepth is not None:
+        data["invdepth"] = scene.invdepth.cpu()
+    if scene.traj is not None:
+        data["traj"] = scene.traj.reshape(G_ * S, 4, 4).cpu()
+    kw = dict(temporal_smoothing_weight=scene.tsw, translation_weight=scene.tw, base_scale=scene.base_scale, conf_clamp=scene.conf_clamp)
+    return P, data, kw
+
+
+def test_clip_alignment_full_size_vs_oracle(dev):
+    """The clip chain at BASELINE clip size against the oracle (the clip mode only asserted finiteness): a 64-frame clip =
+    14 sliding windows of 16 at 320x512 (36.7 M residuals, BASELINE.json configs[2]'s window structure) of the consistent synthetic scene
+    bench.py's clip mode aligns, through post_optimization exactly as the bench calls it. Checked at full size:
+      * the engine's objective and EVERY gradient at the initialised state == oracle/align.py's alignment_loss + autograd on the CPU;
+      * after 40 Adam iterations with both late terms switched on at iteration 20: the oracle objective evaluated at the ENGINE's
+        parameters and window state == the engine's own loss there, and that loss fell;
+      * the recovered camera track is the scene's (a camera sliding 0.01 per frame along x): consecutive centres equidistant and collinear."""
+    import bench
+    from conftest import cpu_threads
+    from geo4d_amd.align import post_optimization
+    from geo4d_amd.pipeline import window_slices
+    from oracle import align as oalign
+    cpu_threads()
+    N, T, H, W = 64, 16, 320, 512
+    slices = window_slices(N, 4, T)
+    assert len(slices) == 14
+    maps, traj = bench.synthetic_scene_maps(slices, T, H, W, dev)
+    scene = post_optimization(slices, maps, traj, dict(n_iter=40, pose_schedule="linear", temporal_smoothing_weight=0.015, translation_weight=1.0),
+                              align=False, depth_traj_start_iter=20)
+    loss0, grads0 = scene.loss_and_grads()
+    P, data, kw = _oracle_view(scene)
+    lo = oalign.alignment_loss(P, data, state=None, **kw)
+    lo.backward()
+    errs = {k: rel(grads0[k].cpu(), P[k].grad) for k in grads0}
+    print(f"[clip 64x320x512, init] loss engine {float(loss0):.6f} vs oracle {float(lo):.6f}; gradient rel errors " + " ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
+    assert abs(float(loss0) - float(lo)) < 2e-5 * abs(float(lo))
+    assert max(errs.values()) < 2e-4, errs
+    del P, lo
+    final, hist = scene.compute_global_alignment(niter=40, schedule="linear", lr=0.03, history=True)
+    assert scene.state is not None and all(h == h for h in hist) and hist[-1] < hist[0]
+    loss1, _ = scene.loss_and_grads()
+    P, data, kw = _oracle_view(scene, requires_grad=False)
+    state = dict(invalid_depth_groups=list(scene.state["invalid_depth_groups"]), valid_traj_groups=list(scene.state["valid_traj_groups"]))
+    with torch.no_grad():
+        l1 = oalign.alignment_loss(P, data, state=state, **kw)
+    print(f"[clip 64x320x512, after 40 iterations, late terms on at 20] loss {hist[0]:.5f} -> engine {float(loss1):.6f} vs oracle at the engine's parameters {float(l1):.6f}; "
+          f"windows without depth fit {state['invalid_depth_groups']}, windows with trajectory term {len(state['valid_traj_groups'])}")
+    assert abs(float(loss1) - float(l1)) < 5e-5 * abs(float(l1))
+    c = scene.get_im_poses_matrix()[:, :3, 3].cpu().double()
+    d = c[1:] - c[:-1]
+    step = d.norm(dim=1)
+    cosang = (d[1:] * d[:-1]).sum(1) / (step[1:] * step[:-1])
+    print(f"[clip] camera steps: mean {float(step.mean()):.5f}, spread {float(step.std() / step.mean()):.3f}; min cos between consecutive steps {float(cosang.min()):.4f}")
+    assert torch.isfinite(c).all() and float(step.std() / step.mean()) < 1.0 and float(cosang.min()) > 0.0       # (a sliding camera, not a random walk)

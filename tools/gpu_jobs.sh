@@ -4,7 +4,7 @@
 # (Rounds 2-3 kept one script per call under tools/r0*_runs/: those are in the history; this file replaces the pattern.)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 JOB=${1:?job name}; shift
-TAG=${TAG:-r4_$JOB}
+TAG=${TAG:-r5_$JOB}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -26,6 +26,36 @@ case $JOB in
     ;;
   attn)
     timeout 600 python tools/attn_bench.py "$@" > $O/attn.log 2>&1; show $O/attn.log
+    ;;
+  r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
+    ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
+    timeout 300 python tools/gemm_bench.py --dtype bf16x3 --presplit --iters 10 --filter conv3x3 > $O/census_x3_conv.log 2>&1; show $O/census_x3_conv.log | tail -16
+    timeout 600 python tools/gemm_bench.py --dtype f16x2 --iters 10 --explore-all --filter conv3x3 > $O/census_x2_conv.log 2>&1; show $O/census_x2_conv.log | grep -v "^    table" | tail -32
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_before.json
+    timeout 900 python tools/tune_gemm.py $O/gfx950.json --keep bf16x3m > $O/tune.log 2>&1; show $O/tune.log | tail -4
+    [ -s $O/gfx950.json ] && cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    ( time timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "vs_reference or 50_step or multi_step" ) > $O/pytest_fullsize.log 2>&1; echo "pytest rc=$?" >> $O/pytest_fullsize.log
+    grep -E "^\[|passed|failed|rc=|Error|assert" $O/pytest_fullsize.log | cut -c1-400 | tail -14
+    for i in 1 2; do
+      for m in bf16x3 bf16x3m; do
+        timeout 400 python bench.py --steps 3 --warmup 1 --dtype $m --no-cpu-baseline --no-fast-mode > $O/bench_${m}_$i.json 2> $O/bench_${m}_$i.err
+        python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_${m}_$i.json")); r = d["roofline"]
+    print("$m run $i:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "issued", round(r["frac_issued"], 3), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print("$m run $i failed", e)
+PY
+      done
+    done
+    cd /tmp
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-shipped-setting > $O/kt.log 2>&1
+    find /tmp/prof/kt -name "*kernel_stats.csv" -exec cp {} $O/kt_kernel_stats.csv \;
+    KT=$(find /tmp/prof/kt -name "*kernel_trace.csv" | head -1)
+    [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
+    head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
   r4a)         # first call of round 4: where do the linears stand (all generations, vendor), is the table mis-tuned, what does a re-tune buy
     timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench_old_table.json 2> $O/bench_old.err; cut -c1-400 $O/bench_old_table.json

@@ -17,7 +17,11 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "gfx950.json")
     dev = torch.device("cuda:0")
     old = dict(ops._tune_table())
-    ops._TUNE = {}                       # re-measure every shape this run touches; shapes it does not touch keep their entry
+    keep = "--keep" in sys.argv          # --keep: only shapes MISSING from the table are measured (a new mode's launches), the rest keep their entry
+    if keep:
+        sys.argv.remove("--keep")
+    else:
+        ops._TUNE = {}                   # re-measure every shape this run touches; shapes it does not touch keep their entry
     for dtype in (sys.argv[2:] or ["bf16"]):
         model, pvae = bench.build(dtype, dev)
         T, h, w = 16, 40, 64
@@ -31,7 +35,7 @@ def main():
         decode_modalities(model, y, pvae)
         torch.cuda.synchronize()
         del model, pvae
-    fresh = dict(ops._TUNE)
+    fresh = {k: v for k, v in ops._TUNE.items() if (not keep or k not in old)}
     changed = sum(1 for k, v in fresh.items() if old.get(k) != v)
     ops._TUNE = {**old, **fresh}
     print(f"re-measured {len(fresh)} shapes, {changed} changed")
