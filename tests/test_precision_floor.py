@@ -40,3 +40,41 @@ def test_single_pass_16bit_cannot_meet_the_bar_but_split_bf16_does():
     print(f"point-map rel L2: f16 weights only {e_w:.2e}, f16 GEMM inputs only {e_a:.2e}, bf16 hi+lo operands {e_3:.2e}")
     assert e_w > 1e-3 and e_a > 1e-3, "a single f16 pass would meet the bar after all: revisit geo4d_amd/precision.py"
     assert e_3 < 1e-4
+
+
+def test_two_pass_f16_is_affordable_on_the_3x3_convolutions_only():
+    """VERDICT r4 #8 (decided on the CPU before any kernel was written): rounding ONLY the A operand of a class of GEMMs to f16 (weights
+    kept to ~22 bits as f16 hi + lo: the two-pass product a_hi.(w_hi + w_lo) of include/geo4d_hip.h dtype 4), everything else as in the
+    bf16x3 mode. On the simulated window (3 DDIM steps + decode, the setting of test_parity_gpu.py::test_window_end_to_end_vs_oracle):
+    the 44 ResBlock convolutions of the U-Net + the VAE decoder's ResnetBlock convolutions (= what the bf16x3m mode does) stay inside
+    5e-4; the same rounding on the projections alone already costs more than that, on every GEMM > 6e-4 - so the mode takes the
+    convolutions (33 % of the FLOPs, the MFMA-bound launches) and nothing else. GPU, full size, 50 steps: tests/test_fullsize_gpu.py."""
+    import precision_sim as ps
+    from oracle import ddim as oddim
+    from oracle.params import seeded_state_dict
+    G = os.path.join(ps.ROOT, "tests", "golden")
+    u = torch.load(os.path.join(G, "unet_tiny.pt"), weights_only=False)
+    v = torch.load(os.path.join(G, "vae_tiny.pt"), weights_only=False)
+    usd, vsd = seeded_state_dict(u["shapes"]), seeded_state_dict(v["shapes"])
+    psd = seeded_state_dict(dict(v["shapes"]), gain=0.9)
+    cfg = u["unet_config"]
+    gen = torch.Generator().manual_seed(777)
+    B, T, h, w = 1, 16, 8, 8
+    x_T = torch.randn((B, 16, T, h, w), generator=gen)
+    ctx = torch.randn((B, 77 + 16 * T, cfg["context_dim"]), generator=gen)
+    zc = torch.randn((B, 4, T, h, w), generator=gen)
+    fs = torch.tensor([24])
+
+    def pts(sc):
+        S_u = ps.S_(usd, sc)
+        am = lambda x, t: ps.unet_forward(S_u, cfg, torch.cat([x, zc], 1), t, ctx, fs, sc)
+        lat = oddim.ddim_sample(am, oddim.make_schedule(), oddim.make_scale_arr(), 3, x_T, eta=0.0)
+        return ps.decode_modalities(vsd, psd, v["ddconfig"], v["adaptorconfig"], lat, sc)[:, :3]
+    ref = pts(ps.Scheme())
+    X = lambda **k: ps.Scheme("bf16x2", "bf16x2", "f32", **k)
+    e_mode = ps.rel(pts(X(c3a="f16", c3w="f16x2", vae3=True)), ref)          # the bf16x3m mode
+    e_proj = ps.rel(pts(X(two_pass=("proj",))), ref)
+    e_all = ps.rel(pts(X(c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ff", "proj"))), ref)
+    print(f"point-map rel L2, two-pass f16 on: U-Net + VAE 3x3 convs {e_mode:.2e} | projections only {e_proj:.2e} | every GEMM {e_all:.2e}")
+    assert e_mode < 5e-4, "the mixed-pass mode lost its margin on the simulated window: revisit geo4d_amd/precision.py bf16x3m"
+    assert e_proj > e_mode * 1.2 and e_all > 6e-4
