@@ -86,8 +86,6 @@ def main():
     for name, kind, geo, N, Cin, cnt in SHAPES:
         if args.filter and args.filter not in name:
             continue
-        if x2 and kind != "c3":
-            continue
         if kind == "c3":
             F_, H, W = geo
             M, K = F_ * H * W, 9 * Cin
@@ -104,7 +102,7 @@ def main():
             w = wcast(torch.randn((N, K), device=dev) / K ** 0.5)
             b = torch.randn((N,), device=dev)
             xa = acast(x)
-            fn = lambda tile=args.tile, split=args.split: ops.conv_gemm(xa, w, torch.empty((M, N), device=dev, dtype=dt), M=M, N=N, K=K, Cin=Cin, lda=Cin, ldw=w.stride(0), ldo=N, T=T, Hin=HW, Win=1, Hout=HW, Wout=1, KT=3, pt=1, bias=b, residual=x, ldr=Cin, tile_hint=tile, split_k=split)
+            fn = lambda tile=args.tile, split=args.split: ops.conv_gemm(xa, w, torch.empty((M, N), device=dev, dtype=dt), M=M, N=N, K=K, Cin=Cin, lda=xa.stride(0), ldw=w.stride(0), ldo=N, T=T, Hin=HW, Win=1, Hout=HW, Wout=1, KT=3, pt=1, bias=b, residual=x, ldr=Cin, tile_hint=tile, split_k=split)
         else:
             M, K = geo, Cin
             x = torch.randn((M, K), device=dev).to(dt)

@@ -57,6 +57,10 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5b)         # does the two-pass f16 form buy the short-K linears / temporal convs anything at the same bytes? (census A/B on one box)
+    timeout 400 python tools/gemm_bench.py --dtype bf16x3 --presplit --iters 10 > $O/census_x3_all.log 2>&1; show $O/census_x3_all.log | tail -32
+    timeout 1200 python tools/gemm_bench.py --dtype f16x2 --iters 10 --explore-all > $O/census_x2_all.log 2>&1; show $O/census_x2_all.log | grep -v "^    table" | tail -64
+    ;;
   r4a)         # first call of round 4: where do the linears stand (all generations, vendor), is the table mis-tuned, what does a re-tune buy
     timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/bench_old_table.json 2> $O/bench_old.err; cut -c1-400 $O/bench_old_table.json
     TAG=$TAG bash $0 census bf16x3
