@@ -101,7 +101,7 @@ SIGNATURES = {
     "geo4d_layernorm": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_layernorm_split": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_void_p,
-                                        C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_int,
                                      C.c_void_p]),
     "geo4d_softmax_rows_causal": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_int,

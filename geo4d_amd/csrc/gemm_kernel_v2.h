@@ -70,7 +70,8 @@ inline bool colsum_fast_ok(const geo4d_conv_gemm_t& p, int sp) {
 }
 // The two-pass f16 type has no 256x256 instantiation (that tile spills a few registers around its K loop, and the long-K convolutions
 // the type exists for run on the phased tiles): hint 22 means the 160x320 tile there - same bits, every tile sums in the same order.
-template <typename T> inline int v2_effective_hint(int hint) { return (IsTwoPass<T>::value && hint == 22) ? 23 : hint; }
+// (GEGLU needs wave tiles a multiple of 64 columns wide, which 160x320 is not: 128x128 there.)
+template <typename T> inline int v2_effective_hint(int hint, int act = 0) { return (IsTwoPass<T>::value && hint == 22) ? (act == 2 ? 25 : 23) : hint; }
 inline int v2_wave_rows(int hint) { return hint == 22 ? 64 : hint == 23 ? 80 : hint == 25 ? 64 : (hint == 27 || hint == 28) ? 32 : 0; }
 __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes lr of a 16-lane row, fixed order (DPP: xor 1, xor 2, half mirror, mirror)
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
@@ -79,7 +80,7 @@ __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 la
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));     // row_mirror
     return v;
 }
-template <int MB, int NB, bool OSPLIT, bool VECONLY = false, bool ROWS4 = false>   // VECONLY: the host checked the vector-store conditions (no scalar fallback code); ROWS4: 4-byte element kernels (bf16x3) - the 16-bit-row fast paths are not instantiated
+template <int MB, int NB, bool OSPLIT, bool VECONLY = false, bool ROWS4 = false, bool OH = false>   // OH: the pre-split output's halves are f16 (the two-pass f16 type: o_split = 2) instead of bf16; VECONLY: the host checked the vector-store conditions (no scalar fallback code); ROWS4: 4-byte element kernels (bf16x3) - the 16-bit-row fast paths are not instantiated
 __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f32x4 (&acc)[MB][NB], const int m_w0, const int n_w0,
                                              const long e_bz, const int e_kz, const bool partial, const int lr, const int lq) {
     const int odt = partial ? GEO4D_F32 : p.out_dtype;
@@ -98,9 +99,19 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
     // this lane's 16-byte chunk `lq` of a block's 64 output bytes (4-byte rows)
     auto chunk_of = [&](const float (&e)[4]) __attribute__((always_inline)) -> u32x4 {
         if constexpr (OSPLIT) {
-            const unsigned int h0 = f32x2_to_bf16x2(e[0], e[1]), h1 = f32x2_to_bf16x2(e[2], e[3]);
-            const unsigned int l0 = f32x2_to_bf16x2(e[0] - __uint_as_float(h0 << 16), e[1] - __uint_as_float(h0 & 0xffff0000u));
-            const unsigned int l1 = f32x2_to_bf16x2(e[2] - __uint_as_float(h1 << 16), e[3] - __uint_as_float(h1 & 0xffff0000u));
+            unsigned int h0, h1, l0, l1;
+            if constexpr (OH) {      // f16 hi | lo of the value clamped to the f16 range (store_split4_f16's arithmetic)
+                float c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = fminf(fmaxf(e[j], -65504.0f), 65504.0f);
+                h0 = f32x2_to_f16x2(c[0], c[1]); h1 = f32x2_to_f16x2(c[2], c[3]);
+                l0 = f32x2_to_f16x2(c[0] - f16_bits_to_f32((unsigned short)(h0 & 0xffffu)), c[1] - f16_bits_to_f32((unsigned short)(h0 >> 16)));
+                l1 = f32x2_to_f16x2(c[2] - f16_bits_to_f32((unsigned short)(h1 & 0xffffu)), c[3] - f16_bits_to_f32((unsigned short)(h1 >> 16)));
+            } else {
+                h0 = f32x2_to_bf16x2(e[0], e[1]); h1 = f32x2_to_bf16x2(e[2], e[3]);
+                l0 = f32x2_to_bf16x2(e[0] - __uint_as_float(h0 << 16), e[1] - __uint_as_float(h0 & 0xffff0000u));
+                l1 = f32x2_to_bf16x2(e[2] - __uint_as_float(h1 << 16), e[3] - __uint_as_float(h1 & 0xffff0000u));
+            }
             // rows of 16 lanes = lq: odd rows of (h) <-> even rows of (l): even lq ends with [h own | h of lq + 1] = the group's hi chunk,
             // odd lq with [l of lq - 1 | l own] = its lo chunk (every lane of the wave takes part: no divergence before this point)
             const u32x2 s0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false);
@@ -314,7 +325,8 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
                     }
                     const long oidx = obase + (long)m * ldo + oc;
                     if (vec_ok) {
-                        if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
+                        if constexpr (OSPLIT && OH) store_split4_f16((float*)O + obase + (long)m * ldo, oc >> 2, e);
+                        else if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
                         else if (odt == GEO4D_F32) *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
                         else if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
                         else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
@@ -354,7 +366,8 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
 #pragma unroll
                         for (int j = 0; j < 4; ++j) e[j] += r[j];
                     }
-                    if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, n >> 2, e);     // (OSPLIT launches are never partial)
+                    if constexpr (OSPLIT && OH) store_split4_f16((float*)O + obase + (long)m * ldo, n >> 2, e);
+                    else if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, n >> 2, e);     // (OSPLIT launches are never partial)
                     else *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
                 } else {
                     if (has_res) {
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
 
     const bool partial = splits > 1;                  // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
     auto epilogue = [&](int e_tm, int e_tn, long e_bz, int e_kz) {
-        reg_epilogue<MB, NB, OSPLIT, false, IsX3<T>::value>(p, acc, e_tm * BM + wr * WTM, e_tn * BN + wc * WTN, e_bz, e_kz, partial, lr, lq);
+        reg_epilogue<MB, NB, OSPLIT, false, IsX3<T>::value, IsTwoPass<T>::value>(p, acc, e_tm * BM + wr * WTM, e_tn * BN + wc * WTN, e_bz, e_kz, partial, lr, lq);
     };
 
     // ---- persistent tile loop --------------------------------------------------------------------------------------------------------
@@ -668,8 +681,13 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
         return GEO4D_EINVAL;
     }
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
-    if constexpr (IsTwoPass<T>::value) {       // f16x2: one instantiation per tile (pre-split x pre-split, plain f32 rows out)
-        if (p.o_split || !p.a_split || !p.w_split) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands and writes plain f32 rows"); return GEO4D_EINVAL; }
+    if constexpr (IsTwoPass<T>::value) {       // f16x2: pre-split x pre-split; plain f32 rows out, or (o_split = 2) the f16 pre-split format
+        if (!p.a_split || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands; o_split 0 or 2 (f16 halves)"); return GEO4D_EINVAL; }
+        if (p.o_split) {
+            if (o_split_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+            geo4d_set_error("conv_gemm: o_split needs no split-K, N % 8 == 0 and 32-byte aligned output rows");
+            return GEO4D_EINVAL;
+        }
         return launch_v2_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
     } else {
     if constexpr (IsX3<T>::value) {
@@ -692,7 +710,7 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 template <typename T>
 int launch_v2_typed(const geo4d_conv_gemm_t& p_in, hipStream_t stream) {
     geo4d_conv_gemm_t p = p_in;
-    p.tile_hint = v2_effective_hint<T>(p_in.tile_hint);
+    p.tile_hint = v2_effective_hint<T>(p_in.tile_hint, p_in.act);
     if constexpr (std::is_same<T, float>::value || std::is_same<T, f16_t>::value) {
         geo4d_set_error("conv_gemm: tile hints 22..28 serve bf16 / bf16x3 (the exact-f32 and the f16 modes stay on hints 0..17)");
         return GEO4D_EINVAL;

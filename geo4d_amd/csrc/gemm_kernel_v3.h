@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
             // (dozens of 64-bit row offsets) are hoisted out of the tile loop and live - spilled - across the K loop
             int lr_ = lr, lq_ = lq;
             asm volatile("" : "+v"(lr_), "+v"(lq_));
-            reg_epilogue<MB, NB, OSPLIT, true, IsX3<T>::value>(p, acc, tmC * BM + wr * WTM, tnC * BN + wc * WTN, bzC, kzC, partial, lr_, lq_);
+            reg_epilogue<MB, NB, OSPLIT, true, IsX3<T>::value, IsTwoPass<T>::value>(p, acc, tmC * BM + wr * WTM, tnC * BN + wc * WTN, bzC, kzC, partial, lr_, lq_);
         }
         // a REAL s_waitcnt vmcnt(0) (the builtin, which the compiler's wait-count pass tracks; an inline-asm one it does not see):
         // without it the pass has to assume pending loads into VGPRs at the K loop's header and drains the DMA queue every slab
@@ -497,7 +497,12 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     }
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
     if constexpr (IsTwoPass<T>::value) {
-        if (p.o_split || !p.a_split || !p.w_split) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands and writes plain f32 rows"); return GEO4D_EINVAL; }
+        if (!p.a_split || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands; o_split 0 or 2 (f16 halves)"); return GEO4D_EINVAL; }
+        if (p.o_split) {
+            if (o_split_ok(p, splits)) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+            geo4d_set_error("conv_gemm: o_split needs no split-K, N % 8 == 0 and 32-byte aligned output rows");
+            return GEO4D_EINVAL;
+        }
         return launch_v3_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
     } else {
     if constexpr (IsX3<T>::value) {

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---- LayerNorm: one wave per row, row held in registers ------------------------------------
-template <typename T, int MAXC, bool SPLIT = false>  // MAXC = chunks per lane; SPLIT (f32 only): write the pre-split bf16x3 operand format
+template <typename T, int MAXC, int SPLIT = 0>  // MAXC = chunks per lane; SPLIT (f32 only): write a pre-split operand format (1: bf16 hi | lo, 2: f16 hi | lo)
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int M, int C,
                                                  float eps, const float* __restrict__ gamma, const float* __restrict__ beta) {
     constexpr int EPC = Elem<T>::EPC;
@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
                 const int c = cc * EPC + j;
                 o[j] = (e[i][j] - mean) * rstd * gamma[c] + beta[c];
             }
-            if constexpr (SPLIT) store_split4(y + row * ldy, cc, o);
+            if constexpr (SPLIT == 1) store_split4(y + row * ldy, cc, o);
+            else if constexpr (SPLIT == 2) store_split4_f16(y + row * ldy, cc, o);
             else *(u32x4*)(y + row * ldy + cc * EPC) = f32_to_chunk<T>(o);
         }
     }
@@ -352,7 +353,7 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     return GEO4D_OK;
 }
 
-template <typename T, bool SPLIT = false>
+template <typename T, int SPLIT = 0>
 int layernorm_typed(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* g, const float* b,
                     hipStream_t s) {
     constexpr int EPC = Elem<T>::EPC;
@@ -423,12 +424,13 @@ extern "C" int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M
 }
 
 extern "C" int geo4d_layernorm_split(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
-                                     const float* beta, void* stream) {
-    if (M <= 0 || C <= 0 || C % 8 || (ldx * 4) % 16 || (ldy * 4) % 16 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) {
-        geo4d_set_error("layernorm_split: bad arguments (f32 input, C % 8 == 0, 16-byte aligned rows)");
+                                     const float* beta, int fmt, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || (ldx * 4) % 16 || (ldy * 4) % 16 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16) || (fmt != 1 && fmt != 2)) {
+        geo4d_set_error("layernorm_split: bad arguments (f32 input, C % 8 == 0, 16-byte aligned rows, fmt 1 = bf16 halves or 2 = f16 halves)");
         return GEO4D_EINVAL;
     }
-    return layernorm_typed<float, true>(x, ldx, y, ldy, M, C, eps, gamma, beta, (hipStream_t)stream);
+    if (fmt == 2) return layernorm_typed<float, 2>(x, ldx, y, ldy, M, C, eps, gamma, beta, (hipStream_t)stream);
+    return layernorm_typed<float, 1>(x, ldx, y, ldy, M, C, eps, gamma, beta, (hipStream_t)stream);
 }
 
 static int softmax_rows_launch(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,

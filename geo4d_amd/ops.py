@@ -238,7 +238,8 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     if isinstance(a, SplitAct) and a.dtype == torch.float16:
         # two-pass f16 (dtype 4): a GroupNorm output in the f16 pre-split format x a pack.split_f16 weight (which carries its 1 / scale)
         assert w.dtype == torch.float16 and hasattr(w, "_x2_alpha"), "an f16 SplitAct multiplies a pack.split_f16 weight"
-        assert not isinstance(out, SplitAct) and out.dtype == torch.float32 and not out_nchw, "the two-pass f16 GEMM writes plain f32 rows"
+        assert (out.dtype == torch.float16 if isinstance(out, SplitAct) else out.dtype == torch.float32) and not out_nchw, \
+            "the two-pass f16 GEMM writes plain f32 rows or the f16 pre-split format"
         assert lda % 2 == 0 and ldw % 2 == 0 and a_bs % 2 == 0 and w_bs % 2 == 0
         a_split = w_split = True
         code = F16X2
@@ -283,9 +284,10 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.alpha, p.split_k = alpha, split_k
     p.debug_ablate = DEBUG_ABLATE
     p.a_split, p.w_split = int(a_split), int(w_split)
-    p.o_split = int(isinstance(out, SplitAct))
+    p.o_split = (2 if out.dtype == torch.float16 else 1) if isinstance(out, SplitAct) else 0
     if p.o_split:
-        assert code == BF16X3 and ldo % 2 == 0 and o_bs % 2 == 0
+        assert (code == BF16X3 and p.o_split == 1) or (code == F16X2 and p.o_split == 2), "pre-split outputs: bf16 halves from bf16x3 launches, f16 halves from two-pass f16 launches"
+        assert ldo % 2 == 0 and o_bs % 2 == 0
         p.ldo, p.o_bs, p.out_dtype = ldo // 2, o_bs // 2, F32
     p.gn_colsum = 0
     ws, zeros = workspace(a.device)
@@ -298,7 +300,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     if tile_hint == 0 and split_k == 0:
         key = f"{p.dtype}/{p.out_dtype}|{M}x{N}x{K}|c{Cin}|t{KT}{KH}{KW}s{stride}u{ups}|a{act}r{int(residual is not None)}n{int(out_nchw)}|b{batch}"
         if code in (BF16X3, F16X2):
-            key += f"|x{int(a_split)}{int(w_split)}" + ("o" if p.o_split else "")
+            key += f"|x{int(a_split)}{int(w_split)}" + ("o" if p.o_split else "")       # (dtype 4's "o" = its f16 halves)
         cfg = _tune_table().get(key)
         if cfg is None and code == BF16X3 and a_split and w_split:
             # pre-split activations: same tile geometry as the raw-activation launch of the same shape (table measured on those)
@@ -313,6 +315,8 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
             cfg = _tune_table().get("3" + key[1:])
             if cfg is not None and cfg[0] < 22:
                 cfg = None                   # (the two-pass kernels exist on the second / third generation only: library default)
+            elif cfg is not None and p.o_split and cfg[1] > 1:
+                cfg = (cfg[0], 1)            # (a pre-split output has no split-K form)
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
@@ -360,7 +364,7 @@ def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, a
     assert kdim(w, x) == K, (w.shape, x.shape)
     if out is None:
         nout = N // 2 if act == 2 else N
-        out = new_split(M, nout, x.device) if split_out else torch.empty((M, nout), device=x.device, dtype=_out_dtype(x, out_dtype))
+        out = new_split(M, nout, x.device, split_fmt(split_out)[1]) if split_out else torch.empty((M, nout), device=x.device, dtype=_out_dtype(x, out_dtype))
     return conv_gemm(x, w, out, M=M, N=N, K=K, Cin=K, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), bias=bias,
                      residual=residual, ldr=_ld(residual) if residual is not None else 0, act=act, alpha=alpha,
                      tile_hint=tile_hint, split_k=split_k, gn_stats=gn_stats)
@@ -458,10 +462,10 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, split_out=False):
     if split_out or isinstance(out, SplitAct):
         assert x.dtype == torch.float32
         if out is None:
-            out = new_split(M, Cc, x.device)
+            out = new_split(M, Cc, x.device, split_fmt(split_out)[1])
         _split_out_ok(out, M)
         _lib.check(lib.geo4d_layernorm_split(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out) // 2, M, Cc, eps, gamma.data_ptr(),
-                                             beta.data_ptr(), _stream()), "geo4d_layernorm_split")
+                                             beta.data_ptr(), 2 if out.dtype == torch.float16 else 1, _stream()), "geo4d_layernorm_split")
         return out
     if out is None:
         out = torch.empty((M, Cc), device=x.device, dtype=x.dtype)

@@ -49,6 +49,28 @@ def pack_conv2d_x2(w, dtype, cin_pad=None):
     return split_f16(w.reshape(co, kh * kw * cp))
 
 
+def pack_conv3d_t_x2(w, dtype):
+    """nn.Conv3d weight [Cout, Cin, 3, 1, 1] -> the two-pass f16 operand, same K order as pack_conv3d_t."""
+    co, ci, kt, kh, kw = w.shape
+    assert kh == 1 and kw == 1
+    return split_f16(w.reshape(co, ci, kt).permute(0, 2, 1).reshape(co, kt * ci))
+
+
+def pack_linear_x2(w, dtype):
+    """nn.Linear / 1x1 conv / Conv1d(k = 1) weight -> the two-pass f16 operand, same layout as pack_linear."""
+    w = w.reshape(w.shape[0], -1)
+    kp = pad_to(w.shape[1], k_align(dtype))
+    if kp != w.shape[1]:
+        w = torch.nn.functional.pad(w, (0, kp - w.shape[1]))
+    return split_f16(w)
+
+
+def pack_geglu_x2(w, b, dtype):
+    inner = w.shape[0] // 2
+    perm = geglu_perm(inner, w.device)
+    return pack_linear_x2(w[perm], dtype), b[perm].float().contiguous()
+
+
 def cast(w, dtype):
     """2-D K-major weight -> operand format of the compute mode (``dtype``: Precision, name or torch dtype)."""
     prec = resolve(dtype)

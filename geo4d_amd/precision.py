@@ -34,6 +34,13 @@ import os
 import torch
 
 
+# Which classes of GEMMs the bf16x3m mode runs in the two-pass f16 form (comma list in $GEO4D_TWO_PASS; A/B runs and the error-budget
+# table of profiles/r05_two_pass_f16.md): conv3x3 = U-Net ResBlock convolutions, vae3x3 = VAE decoder ResnetBlock convolutions,
+# tconv = temporal 3-tap convolutions, proj_in = the transformers' GroupNorm -> proj_in linears, ln = the LayerNorm-fed projections that
+# write plain rows (cross-attention q, temporal q | k | v), ff = the GEGLU feed-forward (both linears).
+TWO_PASS_CLASSES = frozenset(c.strip() for c in os.environ.get("GEO4D_TWO_PASS", "conv3x3,vae3x3,tconv,proj_in,ln,ff").split(",") if c.strip())
+
+
 class Precision:
     __slots__ = ("name", "storage", "x3", "two_pass_conv")
 
@@ -49,6 +56,10 @@ class Precision:
 
     def __hash__(self):
         return hash(self.name)
+
+    def two_pass(self, cls):
+        """Does this mode run GEMM class `cls` (see TWO_PASS_CLASSES) in the two-pass f16 form?"""
+        return bool(self.two_pass_conv) and cls in TWO_PASS_CLASSES
 
 
 BF16 = Precision("bf16", torch.bfloat16)

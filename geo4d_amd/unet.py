@@ -272,20 +272,29 @@ class UNetModel(ParamTree):
         def norm(p):
             return f32(p + ".weight"), f32(p + ".bias")
 
+        # bf16x3m (precision.py): which GEMM classes take the two-pass f16 form - their weights are packed as f16 hi | lo and the
+        # producers of their A operands (GroupNorm / LayerNorm / the GEGLU epilogue) write f16 halves
+        x2 = lambda cls: bool(dt.two_pass(cls) and self.presplit)
+        lin_ln = pack.pack_linear_x2 if x2("ln") else pack.pack_linear
+
         def block(p, cross):
-            b = {}
+            b = {"x2ln": x2("ln"), "x2ff": x2("ff")}
             for a in ("attn1", "attn2"):
                 if a == "attn2" and cross:
-                    b[a + ".q"] = pack.pack_linear(sd[f"{p}.{a}.to_q.weight"], dt)
+                    b[a + ".q"] = lin_ln(sd[f"{p}.{a}.to_q.weight"], dt)            # LayerNorm -> q (plain rows): class "ln"
                 elif cross:      # spatial self-attention: q|k fused, V projected transposed (flash kernel wants V^T)
                     b[a + ".qk"] = pack.pack_linear(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"]], 0), dt)
                     b[a + ".v"] = pack.pack_linear(sd[f"{p}.{a}.to_v.weight"], dt)
-                else:
-                    b[a + ".qkv"] = pack.pack_linear(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"],
-                                                                sd[f"{p}.{a}.to_v.weight"]], 0), dt)
+                else:            # temporal attention: LayerNorm -> q | k | v (plain rows): class "ln"
+                    b[a + ".qkv"] = lin_ln(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"],
+                                                      sd[f"{p}.{a}.to_v.weight"]], 0), dt)
                 b[a + ".o"] = (pack.pack_linear(sd[f"{p}.{a}.to_out.0.weight"], dt), f32(f"{p}.{a}.to_out.0.bias"))
-            b["ff1"] = pack.pack_geglu(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], dt)
-            b["ff2"] = (pack.pack_linear(sd[p + ".ff.net.2.weight"], dt), f32(p + ".ff.net.2.bias"))
+            if x2("ff"):
+                b["ff1"] = pack.pack_geglu_x2(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], dt)
+                b["ff2"] = (pack.pack_linear_x2(sd[p + ".ff.net.2.weight"], dt), f32(p + ".ff.net.2.bias"))
+            else:
+                b["ff1"] = pack.pack_geglu(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], dt)
+                b["ff2"] = (pack.pack_linear(sd[p + ".ff.net.2.weight"], dt), f32(p + ".ff.net.2.bias"))
             for n in ("norm1", "norm2", "norm3"):
                 b[n] = norm(f"{p}.{n}")
             return b
@@ -300,7 +309,7 @@ class UNetModel(ParamTree):
             elif L.kind == "res":
                 e["gn1"], e["gn2"] = norm(p + ".in_layers.0"), norm(p + ".out_layers.0")
                 # bf16x3m: the ResBlocks' two 3x3 convolutions take the two-pass f16 form (precision.py; their GroupNorms then write f16 hi | lo)
-                pk = pack.pack_conv2d_x2 if (dt.two_pass_conv and self.presplit) else pack.pack_conv2d
+                pk = pack.pack_conv2d_x2 if x2("conv3x3") else pack.pack_conv2d
                 e["x2"] = pk is pack.pack_conv2d_x2
                 e["w1"], e["b1"] = pk(sd[p + ".in_layers.2.weight"], dt), f32(p + ".in_layers.2.bias")
                 e["w2"], e["b2"] = pk(sd[p + ".out_layers.3.weight"], dt), f32(p + ".out_layers.3.bias")
@@ -310,12 +319,15 @@ class UNetModel(ParamTree):
                     e["skip"] = (pack.pack_linear(sd[p + ".skip_connection.weight"], dt), f32(p + ".skip_connection.bias"))
                 if self.cfg["temporal_conv"]:
                     e["tc"] = []
+                    e["x2t"] = x2("tconv")
+                    pkt = pack.pack_conv3d_t_x2 if e["x2t"] else pack.pack_conv3d_t
                     for name, ci in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
                         q = f"{p}.temopral_conv.{name}"
-                        e["tc"].append((norm(q + ".0"), pack.pack_conv3d_t(sd[f"{q}.{ci}.weight"], dt), f32(f"{q}.{ci}.bias")))
+                        e["tc"].append((norm(q + ".0"), pkt(sd[f"{q}.{ci}.weight"], dt), f32(f"{q}.{ci}.bias")))
             elif L.kind in ("spatial", "temporal"):
                 e["norm"] = norm(p + ".norm")
-                e["in"] = (pack.pack_linear(sd[p + ".proj_in.weight"], dt), f32(p + ".proj_in.bias"))
+                e["x2in"] = x2("proj_in")
+                e["in"] = ((pack.pack_linear_x2 if e["x2in"] else pack.pack_linear)(sd[p + ".proj_in.weight"], dt), f32(p + ".proj_in.bias"))
                 e["out"] = (pack.pack_linear(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias"))
                 e["blk"] = block(p + ".transformer_blocks.0", cross=L.kind == "spatial")
                 if L.kind == "spatial":
@@ -414,14 +426,15 @@ class UNetModel(ParamTree):
         h2, _, _ = ops.conv2d(a, e["w2"], e["b2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True)
         if "tc" in e:
             y = h2
+            spt = "f16" if e.get("x2t") else sp
             for i, (gn, w, b) in enumerate(e["tc"]):
-                a = ops.groupnorm(y, *gn, F=F_, HW=HW, eps=1e-5, frames_per_stat=T, silu=True, split_out=sp)
+                a = ops.groupnorm(y, *gn, F=F_, HW=HW, eps=1e-5, frames_per_stat=T, silu=True, split_out=spt)
                 y = ops.conv_temporal(a, w, b, B=B, T=T, HW=HW, residual=h2 if i == 3 else None, gn_stats=True)
             h2 = y
         return h2
 
     def _ff(self, blk, x):
-        sp = self.presplit
+        sp = "f16" if blk.get("x2ff") else self.presplit      # two-pass f16 feed-forward: LayerNorm and the GEGLU epilogue write f16 halves
         g = ops.linear(ops.layernorm(x, *blk["norm3"], split_out=sp), *blk["ff1"], act=2, split_out=sp)
         return ops.linear(g, *blk["ff2"], residual=x)
 
@@ -429,7 +442,7 @@ class UNetModel(ParamTree):
         F_, N, C_, heads = B * T, H * W, L.inner, L.heads
         blk = e["blk"]
         sp = self.presplit
-        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=N, eps=1e-6, split_out=sp), *e["in"])
+        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=N, eps=1e-6, split_out="f16" if e.get("x2in") else sp), *e["in"])
         n1 = ops.layernorm(x, *blk["norm1"], split_out=sp)
         x3 = self.compute_dtype.x3
         if sp and N % 8 == 0:
@@ -444,7 +457,7 @@ class UNetModel(ParamTree):
             vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
             att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn1.o"], residual=x)
-        q = ops.linear(ops.layernorm(x, *blk["norm2"], split_out=sp), blk["attn2.q"])
+        q = ops.linear(ops.layernorm(x, *blk["norm2"], split_out="f16" if blk.get("x2ln") else sp), blk["attn2.q"])
         k_t, k_i, vt_t, vt_i, _ = kv
         off, _ = e["kv"]
         sets = [(k_t[:, off:off + C_], vt_t[L.prefix].reshape(-1, 80), 77, T, C_ * 80)]
@@ -459,9 +472,9 @@ class UNetModel(ParamTree):
         F_, HW, C_, heads = B * T, H * W, L.inner, L.heads
         blk = e["blk"]
         sp = self.presplit
-        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=HW, eps=1e-6, frames_per_stat=T, split_out=sp), *e["in"])
+        x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=HW, eps=1e-6, frames_per_stat=T, split_out="f16" if e.get("x2in") else sp), *e["in"])
         for a, n in (("attn1", "norm1"), ("attn2", "norm2")):
-            qkv = ops.linear(ops.layernorm(x, *blk[n], split_out=sp), blk[a + ".qkv"])
+            qkv = ops.linear(ops.layernorm(x, *blk[n], split_out="f16" if blk.get("x2ln") else sp), blk[a + ".qkv"])
             att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125, split_out=sp)
             x = ops.linear(att, *blk[a + ".o"], residual=x)
         x = self._ff(blk, x)

@@ -165,7 +165,7 @@ class AutoencoderKL(ParamTree):
 
         def resnet(p, two_pass=False):
             # bf16x3m: the DECODER's ResnetBlock convolutions (decoder.* and decoder_adaptor.*) take the two-pass f16 form (precision.py)
-            pk = pack.pack_conv2d_x2 if (two_pass and dt.two_pass_conv and self.presplit) else pack.pack_conv2d
+            pk = pack.pack_conv2d_x2 if (two_pass and dt.two_pass("vae3x3") and self.presplit) else pack.pack_conv2d
             e = dict(gn1=norm(p + ".norm1"), gn2=norm(p + ".norm2"),
                      c1=(pk(sd[p + ".conv1.weight"], dt), f32(p + ".conv1.bias")),
                      c2=(pk(sd[p + ".conv2.weight"], dt), f32(p + ".conv2.bias")))

@@ -79,7 +79,8 @@ typedef struct geo4d_conv_gemm_t {
     int a_split, w_split;/* dtype 3 (bf16x3): the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32; dtype 4 (f16x2): both must
                             be set (f16 halves: pack.py split_f16 for weights, geo4d_groupnorm_t.split_out = 2 for activations) */
-    int o_split;         /* dtype 3 (bf16x3), a_split and w_split set, out_dtype F32: O is written in the pre-split operand
+    int o_split;         /* 2 (dtype 4 only): the same with f16 halves (values clamped to the f16 range) - the A operand of a following dtype-4
+                            launch (GEGLU -> FF-out). 1: dtype 3 (bf16x3), a_split and w_split set, out_dtype F32: O is written in the pre-split operand
                             format ([8 x bf16 hi | 8 x bf16 lo] per 8 output columns; ldo / o_bs still count columns) - the producer
                             side of a_split (GEGLU -> FF-out chain; q | k and V^T of the spatial attention, geo4d_attention_t.qkv_split).
                             Stored columns % 8 == 0, ldo % 8 == 0, 32-byte aligned rows, no split-K, any epilogue incl. residual;
@@ -122,9 +123,10 @@ int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);
 int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
                     const float* beta, int dtype, void* stream);
 
-/* the same for an f32 x, writing y in the pre-split bf16x3 operand format (see geo4d_groupnorm_t.split_out); C % 8 == 0. */
+/* the same for an f32 x, writing y in a pre-split operand format (geo4d_groupnorm_t.split_out: fmt 1 = bf16 hi | lo, 2 = f16 hi | lo);
+ * C % 8 == 0. */
 int geo4d_layernorm_split(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
-                          const float* beta, void* stream);
+                          const float* beta, int fmt, void* stream);
 
 /* y = softmax(scale * x) per row, x fp32; replaces F.softmax in the VAE AttnBlock (ae_modules.py:66-68). */
 int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,

@@ -170,3 +170,70 @@ def test_full_chip_stream_is_deterministic(dev):
     sub = slice(0, 2)                                                     # two frames of the fp64 reference are enough
     ref = TF.conv2d(a_seen(xt).reshape(F, H, W, C)[sub].permute(0, 3, 1, 2), ws, bc.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, C)
     close("L0 conv3x3", base[: 2 * H * W], ref)
+
+
+def split_halves(t):
+    """(hi, lo) fp64 [M, K] of a pre-split [M, 2K] tensor (either format)."""
+    m, k2 = t.shape
+    g = t.as_subclass(torch.Tensor).reshape(m, k2 // 16, 2, 8).double()
+    return g[:, :, 0].reshape(m, k2 // 2), g[:, :, 1].reshape(m, k2 // 2)
+
+
+@pytest.mark.parametrize("C", [320, 640, 1280])
+def test_layernorm_f16_split_output(dev, C):
+    from geo4d_amd import ops
+    M = 777
+    x = rnd((M, C), dev, 60) * 2.0 + 0.3
+    gamma, beta = rnd((C,), dev, 61) + 1.0, rnd((C,), dev, 62)
+    plain = ops.layernorm(x, gamma, beta)
+    sp = ops.layernorm(x, gamma, beta, split_out="f16")
+    assert isinstance(sp, ops.SplitAct) and sp.dtype == torch.float16 and sp.shape == (M, 2 * C)
+    assert torch.equal(sp.view(torch.int16), split_f16_act(plain).view(torch.int16)), "f16 split output differs from split(plain LayerNorm)"
+    b16 = ops.layernorm(x, gamma, beta, split_out=True)                       # the bf16 format is unchanged
+    hi, lo = split_halves(b16)
+    assert b16.dtype == torch.bfloat16 and rel(hi + lo, plain.double()) < 1e-5
+
+
+@pytest.mark.parametrize("tile", [23, 25, 72, 74])
+def test_temporal_conv_two_pass(dev, tile):
+    from geo4d_amd import ops, pack
+    B, T, HW, C = 2, 7, 45, 128
+    x = rnd((B * T * HW, C), dev, 70)
+    w, b = rnd((C, C, 3, 1, 1), dev, 71, 0.05), rnd((C,), dev, 72)
+    r = rnd((B * T * HW, C), dev, 73)
+    wp = pack.pack_conv3d_t_x2(w, "bf16x3m")
+    out = both_grids(lambda: ops.conv_temporal(split_f16_act(x), wp, b, B=B, T=T, HW=HW, residual=r, tile_hint=tile, split_k=1))
+    ws = weight_seen(wp).reshape(C, 3, C).permute(0, 2, 1).reshape(C, C, 3, 1, 1)           # [Cout, 3, Cin] -> [Cout, Cin, 3, 1, 1]
+    x5 = a_seen(x).reshape(B, T, HW, 1, C).permute(0, 4, 1, 2, 3)
+    ref = TF.conv3d(x5, ws, b.double(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(B * T * HW, C) + r.double()
+    close(f"temporal conv tile{tile}", out, ref)
+
+
+@pytest.mark.parametrize("tile", [0, 25, 27, 71, 74])
+def test_geglu_feed_forward_chain_two_pass(dev, tile):
+    """LayerNorm (f16 halves) -> two-pass GEGLU linear writing f16 halves (o_split = 2) -> two-pass ff-out with the residual: the chain
+    unet._ff runs in the bf16x3m mode, each stage against fp64 math on the operands it reads (the ff-out sees the HI half of what the
+    GEGLU epilogue stored). Tiles whose wave tiles cannot pair value / gate blocks must be refused."""
+    from geo4d_amd import ops, pack
+    M, K, inner = 700, 256, 320
+    x = rnd((M, K), dev, 80)
+    w, b = rnd((2 * inner, K), dev, 81, 0.1), rnd((2 * inner,), dev, 82)
+    w2, b2 = rnd((K, inner), dev, 83, 0.1), rnd((K,), dev, 84)
+    wp, bp = pack.pack_geglu_x2(w, b, "bf16x3m")
+    wp2 = pack.pack_linear_x2(w2, "bf16x3m")
+    xs = split_f16_act(x)
+    g = both_grids(lambda: ops.linear(xs, wp, bp, act=2, split_out="f16", tile_hint=tile, split_k=1 if tile else 0))
+    assert isinstance(g, ops.SplitAct) and g.dtype == torch.float16 and g.shape == (M, 2 * inner)
+    perm = pack.geglu_perm(inner, dev)
+    wu = torch.empty((2 * inner, K), device=dev, dtype=torch.float64)
+    wu[perm] = weight_seen(wp)
+    h = a_seen(x) @ wu.t() + b.double()
+    ref = h[:, :inner] * TF.gelu(h[:, inner:])
+    hi, lo = split_halves(g)
+    close(f"geglu tile{tile}: hi + lo", hi + lo, ref)
+    assert torch.equal(hi.float().to(torch.float16), (hi + lo).float().to(torch.float16)), "hi is not the f16 rounding of the stored value"
+    y = both_grids(lambda: ops.linear(g, wp2, b2, residual=x, tile_hint=tile if tile != 27 else 25, split_k=1 if tile else 0))
+    close(f"ff-out tile{tile}", y, hi @ weight_seen(wp2).t() + b2.double() + x.double())
+    for bad in (23, 72, 73):
+        with pytest.raises(RuntimeError):
+            ops.linear(xs, wp, bp, act=2, split_out="f16", tile_hint=bad, split_k=1)

@@ -57,6 +57,31 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5c)         # two-pass f16 widened to tconv / proj_in / LayerNorm-fed plain-row projections / the GEGLU feed-forward (f16 o_split): correct? accurate? faster?
+    ( time timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_gemm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gemm.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_gemm.log | tail -12
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_before.json
+    timeout 900 python tools/tune_gemm.py $O/gfx950.json --keep bf16x3m > $O/tune.log 2>&1; show $O/tune.log | tail -4
+    [ -s $O/gfx950.json ] && cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    ( time timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "vs_reference or 50_step or multi_step" ) > $O/pytest_fullsize.log 2>&1; echo "pytest rc=$?" >> $O/pytest_fullsize.log
+    grep -E "\[full|\[3-step|\[50-step|passed|failed|rc=|Error|assert" $O/pytest_fullsize.log | cut -c1-700 | tail -14
+    run_bench() {   # name, dtype, extra env
+      env $3 timeout 400 python bench.py --steps 3 --warmup 1 --dtype $2 --no-cpu-baseline --no-fast-mode --no-clip-leg > $O/bench_$1.json 2> $O/bench_$1.err
+      python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_$1.json")); r = d["roofline"]
+    print("$1:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "issued", round(r["frac_issued"], 3), "passes", round(r["mfma_passes_per_product"], 2), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print("$1 failed", e)
+PY
+    }
+    run_bench x3_1 bf16x3 "A=1"
+    run_bench x3m_all_1 bf16x3m "A=1"
+    run_bench x3m_conv_only bf16x3m "GEO4D_TWO_PASS=conv3x3,vae3x3"
+    run_bench x3m_all_2 bf16x3m "A=1"
+    run_bench x3m_no_ff bf16x3m "GEO4D_TWO_PASS=conv3x3,vae3x3,tconv,proj_in,ln"
+    ;;
   r5b)         # does the two-pass f16 form buy the short-K linears / temporal convs anything at the same bytes? (census A/B on one box)
     timeout 400 python tools/gemm_bench.py --dtype bf16x3 --presplit --iters 10 > $O/census_x3_all.log 2>&1; show $O/census_x3_all.log | tail -32
     timeout 1200 python tools/gemm_bench.py --dtype f16x2 --iters 10 --explore-all > $O/census_x2_all.log 2>&1; show $O/census_x2_all.log | grep -v "^    table" | tail -64
