@@ -29,9 +29,15 @@ def k_align(dtype):
     return 32 if _resolve_precision(dtype).storage == torch.float32 else 64
 
 
+def is_x2_weight(w):
+    """A pack.split_f16 weight (float16 [N, 2K] = f16 hi | lo per 8 K-elements, carrying the 1 / scale of its launch)."""
+    return w.dtype == torch.float16 and hasattr(w, "_x2_alpha")
+
+
 def is_split(w, other):
-    """True when `w` is a PRE-SPLIT bf16x3 operand (pack.split_bf16: bf16 [rows, 2K]) multiplied with an f32 operand."""
-    return w.dtype == torch.bfloat16 and other.dtype == torch.float32
+    """True when `w` is a PRE-SPLIT operand (pack.split_bf16: bf16 [rows, 2K]; pack.split_f16: float16 [rows, 2K] of the two-pass f16
+    form) multiplied with a raw f32 operand."""
+    return (w.dtype == torch.bfloat16 or is_x2_weight(w)) and other.dtype == torch.float32
 
 
 class SplitAct(torch.Tensor):
@@ -250,6 +256,13 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         a_split = w_split = True
         code = BF16X3
         lda, a_bs, ldw, w_bs = lda // 2, a_bs // 2, ldw // 2, w_bs // 2
+    elif w_split and is_x2_weight(w):
+        # two-pass f16 with a RAW f32 activation (residual streams: no producer in front that could pre-split): converted to f16 in the
+        # kernel's registers (second-generation tiles)
+        assert not isinstance(out, SplitAct) and out.dtype == torch.float32 and not out_nchw and ldw % 2 == 0 and w_bs % 2 == 0
+        code = F16X2
+        alpha = alpha * w._x2_alpha
+        ldw, w_bs = ldw // 2, w_bs // 2
     elif a_split or w_split:
         code = BF16X3
         if a_split:

@@ -37,8 +37,10 @@ import torch
 # Which classes of GEMMs the bf16x3m mode runs in the two-pass f16 form (comma list in $GEO4D_TWO_PASS; A/B runs and the error-budget
 # table of profiles/r05_two_pass_f16.md): conv3x3 = U-Net ResBlock convolutions, vae3x3 = VAE decoder ResnetBlock convolutions,
 # tconv = temporal 3-tap convolutions, proj_in = the transformers' GroupNorm -> proj_in linears, ln = the LayerNorm-fed projections that
-# write plain rows (cross-attention q, temporal q | k | v), ff = the GEGLU feed-forward (both linears).
-TWO_PASS_CLASSES = frozenset(c.strip() for c in os.environ.get("GEO4D_TWO_PASS", "conv3x3,vae3x3,tconv,proj_in,ln,ff").split(",") if c.strip())
+# write plain rows (cross-attention q, temporal q | k | v), ff = the GEGLU feed-forward (both linears), proj_out = the transformers'
+# proj_out linears (fed pre-split by the ff-out epilogue at levels 0 / 1, raw below), raw = the launches whose activation is a raw f32
+# residual stream converted in the kernel's registers (U-Net down / up samplers and skip connections, VAE upsamplers and shortcuts).
+TWO_PASS_CLASSES = frozenset(c.strip() for c in os.environ.get("GEO4D_TWO_PASS", "conv3x3,vae3x3,tconv,proj_in,ln,ff,proj_out,raw").split(",") if c.strip())
 
 
 class Precision:

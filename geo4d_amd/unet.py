@@ -316,7 +316,7 @@ class UNetModel(ParamTree):
                 emb_w.append(sd[p + ".emb_layers.1.weight"].float()); emb_b.append(sd[p + ".emb_layers.1.bias"].float())
                 e["emb"] = (off, off + L.cout); off += L.cout
                 if L.cin != L.cout:
-                    e["skip"] = (pack.pack_linear(sd[p + ".skip_connection.weight"], dt), f32(p + ".skip_connection.bias"))
+                    e["skip"] = ((pack.pack_linear_x2 if x2("raw") else pack.pack_linear)(sd[p + ".skip_connection.weight"], dt), f32(p + ".skip_connection.bias"))
                 if self.cfg["temporal_conv"]:
                     e["tc"] = []
                     e["x2t"] = x2("tconv")
@@ -328,7 +328,8 @@ class UNetModel(ParamTree):
                 e["norm"] = norm(p + ".norm")
                 e["x2in"] = x2("proj_in")
                 e["in"] = ((pack.pack_linear_x2 if e["x2in"] else pack.pack_linear)(sd[p + ".proj_in.weight"], dt), f32(p + ".proj_in.bias"))
-                e["out"] = (pack.pack_linear(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias"))
+                e["x2out"] = x2("proj_out")
+                e["out"] = ((pack.pack_linear_x2 if e["x2out"] else pack.pack_linear)(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias"))
                 e["blk"] = block(p + ".transformer_blocks.0", cross=L.kind == "spatial")
                 if L.kind == "spatial":
                     a = p + ".transformer_blocks.0.attn2"
@@ -339,9 +340,9 @@ class UNetModel(ParamTree):
                         e["wv_img"] = pack.pack_linear(sd[a + ".to_v_ip.weight"], dt)
                     e["kv"] = (kv_off, L.inner); kv_off += L.inner
             elif L.kind == "down":
-                e["w"], e["b"] = pack.pack_conv2d(sd[p + ".op.weight"], dt), f32(p + ".op.bias")
+                e["w"], e["b"] = (pack.pack_conv2d_x2 if x2("raw") else pack.pack_conv2d)(sd[p + ".op.weight"], dt), f32(p + ".op.bias")
             elif L.kind == "up":
-                e["w"], e["b"] = pack.pack_conv2d(sd[p + ".conv.weight"], dt), f32(p + ".conv.bias")
+                e["w"], e["b"] = (pack.pack_conv2d_x2 if x2("raw") else pack.pack_conv2d)(sd[p + ".conv.weight"], dt), f32(p + ".conv.bias")
             P[p] = e
         P["emb_w"], P["emb_b"] = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
         P["k_text"] = pack.pack_linear(torch.cat(k_text, 0), dt)
@@ -433,10 +434,16 @@ class UNetModel(ParamTree):
             h2 = y
         return h2
 
-    def _ff(self, blk, x):
+    def _ff(self, blk, x, e):
+        """The feed-forward. Its result feeds ONLY the transformer's proj_out: where the ff-out launch is un-split anyway (levels 0 / 1:
+        M >= 8192; a pre-split output has no split-K form) its epilogue writes the pre-split operand format proj_out multiplies (round 5:
+        proj_out used to split a raw f32 activation in its K loop)."""
         sp = "f16" if blk.get("x2ff") else self.presplit      # two-pass f16 feed-forward: LayerNorm and the GEGLU epilogue write f16 halves
         g = ops.linear(ops.layernorm(x, *blk["norm3"], split_out=sp), *blk["ff1"], act=2, split_out=sp)
-        return ops.linear(g, *blk["ff2"], residual=x)
+        chain = False
+        if self.presplit and x.shape[0] >= 8192 and x.shape[1] % 8 == 0:
+            chain = "f16" if (blk.get("x2ff") and e.get("x2out")) else (True if not (blk.get("x2ff") or e.get("x2out")) else False)
+        return ops.linear(g, *blk["ff2"], residual=x, split_out=chain)
 
     def _spatial(self, e, L, h, kv, B, T, H, W):
         F_, N, C_, heads = B * T, H * W, L.inner, L.heads
@@ -465,7 +472,7 @@ class UNetModel(ParamTree):
             sets.append((k_i[:, off:off + C_], vt_i[L.prefix], 16, 1, 16))
         att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
-        x = self._ff(blk, x)
+        x = self._ff(blk, x, e)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)
 
     def _temporal(self, e, L, h, B, T, H, W):
@@ -477,7 +484,7 @@ class UNetModel(ParamTree):
             qkv = ops.linear(ops.layernorm(x, *blk[n], split_out="f16" if blk.get("x2ln") else sp), blk[a + ".qkv"])
             att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125, split_out=sp)
             x = ops.linear(att, *blk[a + ".o"], residual=x)
-        x = self._ff(blk, x)
+        x = self._ff(blk, x, e)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)
 
     def _run(self, P, layers, h, emb_all, kv, B, T, H, W):

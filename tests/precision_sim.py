@@ -71,7 +71,7 @@ class S_:
         return t
 
     def lin(self, x, p, bias=True, cls=None):
-        if cls in self.sc.two_pass:
+        if cls is not None and any(c in self.sc.two_pass for c in ((cls,) if isinstance(cls, str) else cls)):
             x = x.to(torch.float16).float()
         w = self.w(p + ".weight")
         return F.linear(x, w.reshape(w.shape[0], -1), self.sd.get(p + ".bias") if bias else None)
@@ -112,15 +112,19 @@ def _mha(sc, q, k, v, heads):
 
 def _attention(S, x, p, heads, context=None, image_cross=False):
     sc = S.sc
-    q = sc.qa(S.lin(x, p + ".to_q", False, cls="proj"))
+    # classes as the engine groups them (geo4d_amd/precision.py TWO_PASS_CLASSES): "ln" = LayerNorm-fed projections writing plain rows
+    # (cross-attention q; temporal q | k | v - `tself`), "qk1" / "v1" = the spatial self-attention's q | k and V^T, "attn_out" = to_out
+    tself = getattr(S, "_temporal_block", False)
+    q = sc.qa(S.lin(x, p + ".to_q", False, cls=("proj", "ln" if (context is not None or tself) else "qk1")))
     if context is None:
-        out = _mha(sc, q, sc.qa(S.lin(x, p + ".to_k", False, cls="proj")), sc.qa(S.lin(x, p + ".to_v", False, cls="proj")), heads)
+        out = _mha(sc, q, sc.qa(S.lin(x, p + ".to_k", False, cls=("proj", "ln" if tself else "qk1"))),
+                   sc.qa(S.lin(x, p + ".to_v", False, cls=("proj", "ln" if tself else "v1"))), heads)
     else:
         text, img = sc.qa(context[:, :77]), sc.qa(context[:, 77:])
         out = _mha(sc, q, sc.qa(S.lin(text, p + ".to_k", False)), sc.qa(S.lin(text, p + ".to_v", False)), heads)
         if image_cross:
             out = out + _mha(sc, q, sc.qa(S.lin(img, p + ".to_k_ip", False)), sc.qa(S.lin(img, p + ".to_v_ip", False)), heads)
-    return S.lin(sc.qa(out), p + ".to_out.0", cls="proj")
+    return S.lin(sc.qa(out), p + ".to_out.0", cls=("proj", "attn_out"))
 
 
 def _block(S, x, p, heads, context, image_cross):
@@ -137,7 +141,7 @@ def _res(S, x, emb, p, b):
     h = S.conv3x3(F.silu(S.gn(x, p + ".in_layers.0", 1e-5)), p + ".in_layers.2")
     h = sc.qh1(h + F.linear(F.silu(emb), S.sd[p + ".emb_layers.1.weight"], S.sd[p + ".emb_layers.1.bias"])[:, :, None, None])
     h = S.conv3x3(F.silu(S.gn(h, p + ".out_layers.0", 1e-5)), p + ".out_layers.3")
-    skip = x if (p + ".skip_connection.weight") not in S.sd else S.conv2(sc.qa(x), p + ".skip_connection", pad=0)
+    skip = x if (p + ".skip_connection.weight") not in S.sd else S.conv2(sc.qa(x) if "raw" not in sc.two_pass else sc.qa(x).to(torch.float16).float(), p + ".skip_connection", pad=0)
     h = sc.qs(skip + h)
     if (p + ".temopral_conv.conv1.0.weight") in S.sd:
         bt, c, hh, ww = h.shape
@@ -156,9 +160,10 @@ def _spatial(S, x, p, heads, context):
     sc = S.sc
     bt, c, hh, ww = x.shape
     y = sc.qa(S.gn(x, p + ".norm", 1e-6)).permute(0, 2, 3, 1).reshape(bt, hh * ww, c)
-    y = sc.qs(S.lin(y, p + ".proj_in", cls="proj"))
+    y = sc.qs(S.lin(y, p + ".proj_in", cls=("proj", "proj_in")))
+    S._temporal_block = False
     y = _block(S, y, p + ".transformer_blocks.0", heads, context, True)
-    y = S.lin(sc.qa(y), p + ".proj_out", cls="proj")
+    y = S.lin(sc.qa(y), p + ".proj_out", cls=("proj", "proj_out"))
     return sc.qs(y.reshape(bt, hh, ww, c).permute(0, 3, 1, 2) + x)
 
 
@@ -168,9 +173,11 @@ def _temporal(S, x, p, heads, b):
     t = bt // b
     z = x.reshape(b, t, c, hh, ww).permute(0, 2, 1, 3, 4)
     y = sc.qa(S.gn(z, p + ".norm", 1e-6)).permute(0, 3, 4, 2, 1).reshape(b * hh * ww, t, c)
-    y = sc.qs(S.lin(y, p + ".proj_in", cls="proj"))
+    y = sc.qs(S.lin(y, p + ".proj_in", cls=("proj", "proj_in")))
+    S._temporal_block = True
     y = _block(S, y, p + ".transformer_blocks.0", heads, None, False)
-    y = S.lin(sc.qa(y), p + ".proj_out", cls="proj")
+    S._temporal_block = False
+    y = S.lin(sc.qa(y), p + ".proj_out", cls=("proj", "proj_out"))
     y = y.reshape(b, hh, ww, t, c).permute(0, 4, 3, 1, 2)
     return sc.qs(y + z).permute(0, 2, 1, 3, 4).reshape(bt, c, hh, ww)
 
@@ -262,7 +269,8 @@ def vae_features(S, ddconfig, z, prefix="decoder"):
         for blk in range(nres + 1):
             h = _vresnet(S, h, f"{prefix}.up.{lvl}.block.{blk}")
         if lvl != 0:
-            h = sc.qs(S.conv2(F.interpolate(sc.qa(h), scale_factor=2.0, mode="nearest"), f"{prefix}.up.{lvl}.upsample.conv"))
+            hu = sc.qa(h).to(torch.float16).float() if (sc.vae3 and "raw" in sc.two_pass) else sc.qa(h)
+            h = sc.qs(S.conv2(F.interpolate(hu, scale_factor=2.0, mode="nearest"), f"{prefix}.up.{lvl}.upsample.conv"))
     return h
 
 

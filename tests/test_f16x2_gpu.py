@@ -231,9 +231,65 @@ def test_geglu_feed_forward_chain_two_pass(dev, tile):
     ref = h[:, :inner] * TF.gelu(h[:, inner:])
     hi, lo = split_halves(g)
     close(f"geglu tile{tile}: hi + lo", hi + lo, ref)
-    assert torch.equal(hi.float().to(torch.float16), (hi + lo).float().to(torch.float16)), "hi is not the f16 rounding of the stored value"
+    big = (hi + lo).abs() > 1e-3          # (below the f16 normal range lo is itself a rounded subnormal: hi + lo may land one step off hi)
+    assert torch.equal(hi[big].float().to(torch.float16), (hi + lo)[big].float().to(torch.float16)), "hi is not the f16 rounding of the stored value"
     y = both_grids(lambda: ops.linear(g, wp2, b2, residual=x, tile_hint=tile if tile != 27 else 25, split_k=1 if tile else 0))
     close(f"ff-out tile{tile}", y, hi @ weight_seen(wp2).t() + b2.double() + x.double())
     for bad in (23, 72, 73):
         with pytest.raises(RuntimeError):
             ops.linear(xs, wp, bp, act=2, split_out="f16", tile_hint=bad, split_k=1)
+
+
+@pytest.mark.parametrize("tile", [0, 23, 25, 27, 28, 72])
+def test_raw_f32_activation_is_converted_in_the_kernel(dev, tile):
+    """The two-pass form on a RAW f32 activation (residual streams: U-Net down / up samplers, skip connections, proj_out below level 1,
+    the VAE's upsampling convolutions and shortcuts): converted to f16 in the kernel's registers (second-generation tiles; a
+    third-generation hint runs on its twin). Linear + 3x3 convolutions with stride 2 and with the nearest-2x upsampling gather."""
+    from geo4d_amd import ops, pack
+    M, K, N = 1000, 320, 456
+    x, w = rnd((M, K), dev, 90), rnd((N, K), dev, 91, 0.05)
+    b, r = rnd((N,), dev, 92), rnd((M, N), dev, 93)
+    wp = pack.pack_linear_x2(w, "bf16x3m")
+    sk = dict(tile_hint=tile, split_k=1) if tile else {}
+    out = both_grids(lambda: ops.linear(x, wp, b, residual=r, **sk))
+    close(f"raw linear tile{tile}", out, a_seen(x) @ weight_seen(wp).t() + b.double() + r.double())
+    assert torch.equal(out, ops.linear(split_f16_act(x), wp, b, residual=r, **sk)), "raw activation != pre-split activation (same f16 values)"
+    F, H, W, Ci, Co = 3, 10, 8, 128, 96
+    x_nchw = rnd((F, Ci, H, W), dev, 94)
+    wc, bc = rnd((Co, Ci, 3, 3), dev, 95, 0.03), rnd((Co,), dev, 96)
+    xt = x_nchw.permute(0, 2, 3, 1).reshape(F * H * W, Ci).contiguous()
+    wp = pack.pack_conv2d_x2(wc, "bf16x3m")
+    ws = weight_seen(wp).reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    xa = a_seen(xt).reshape(F, H, W, Ci).permute(0, 3, 1, 2)
+    for stride, ups in ((2, 1), (1, 2), (1, 1)):
+        xin = TF.interpolate(xa, scale_factor=2, mode="nearest") if ups == 2 else xa
+        ref = TF.conv2d(xin, ws, bc.double(), stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+        o = both_grids(lambda: ops.conv2d(xt, wp, bc, F=F, Hin=H, Win=W, KH=3, KW=3, stride=stride, pad=1, ups=ups, gn_stats=True, **sk)[0])
+        close(f"raw conv tile{tile} stride{stride} ups{ups}", o, ref)
+
+
+def test_ff_out_feeds_proj_out_pre_split(dev):
+    """Round 5: the ff-out epilogue writes the pre-split format proj_out multiplies (unet._ff `chain`), in both modes: bf16 halves from the
+    bf16x3 launch (bit-identical to the plain output multiplied as a raw activation: the split is the same arithmetic), f16 halves from
+    the two-pass launch (== the raw two-pass launch on the plain output: the same f16 values)."""
+    from geo4d_amd import ops, pack
+    M, C = 8192, 320
+    g, x, h = rnd((M, 4 * C), dev, 100), rnd((M, C), dev, 101), rnd((M, C), dev, 102)
+    w2, b2 = rnd((C, 4 * C), dev, 103, 0.03), rnd((C,), dev, 104)
+    wo, bo = rnd((C, C), dev, 105, 0.05), rnd((C,), dev, 106)
+    for mode in ("bf16x3", "bf16x3m"):
+        if mode == "bf16x3":
+            gs = ops.SplitAct.wrap(pack.split_bf16(g))
+            p2, po = pack.pack_linear(w2, "bf16x3"), pack.pack_linear(wo, "bf16x3")
+            fmt = True
+        else:
+            gs = split_f16_act(g)
+            p2, po = pack.pack_linear_x2(w2, "bf16x3m"), pack.pack_linear_x2(wo, "bf16x3m")
+            fmt = "f16"
+        plain = ops.linear(gs, p2, b2, residual=x)
+        chained = ops.linear(gs, p2, b2, residual=x, split_out=fmt)
+        hi, lo = split_halves(chained)
+        assert rel(hi + lo, plain.double()) < 1e-5, mode
+        y_plain = ops.linear(plain, po, bo, residual=h)
+        y_chain = ops.linear(chained, po, bo, residual=h)
+        assert torch.equal(y_plain, y_chain) or rel(y_chain, y_plain) < 2e-6, (mode, rel(y_chain, y_plain))

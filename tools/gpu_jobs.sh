@@ -57,6 +57,31 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5d)         # + ff-out -> proj_out pre-split chain (both modes), raw-activation two-pass (down / up / skip / VAE upsamplers): correct? accurate (smoke!)? faster?
+    ( time timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_presplit_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_gemm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gemm.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_gemm.log | tail -12
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_before.json
+    timeout 900 python tools/tune_gemm.py $O/gfx950.json --keep bf16x3m bf16x3 > $O/tune.log 2>&1; show $O/tune.log | tail -4
+    [ -s $O/gfx950.json ] && cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -5 $O/smoke.log
+    ( time timeout 900 python -m pytest tests/test_fullsize_gpu.py tests/test_parity_gpu.py -m gpu -q -x -s -k "vs_reference or 50_step or multi_step or window_end_to_end" ) > $O/pytest_fullsize.log 2>&1; echo "pytest rc=$?" >> $O/pytest_fullsize.log
+    grep -E "\[full|\[3-step|\[50-step|rel|passed|failed|rc=|Error|assert" $O/pytest_fullsize.log | cut -c1-700 | tail -16
+    run_bench() {   # name, dtype, extra env
+      env $3 timeout 400 python bench.py --steps 3 --warmup 1 --dtype $2 --no-cpu-baseline --no-fast-mode --no-clip-leg > $O/bench_$1.json 2> $O/bench_$1.err
+      python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_$1.json")); r = d["roofline"]
+    print("$1:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "issued", round(r["frac_issued"], 3), "passes", round(r["mfma_passes_per_product"], 2), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print("$1 failed", e)
+PY
+    }
+    run_bench x3_1 bf16x3 "A=1"
+    run_bench x3m_all_1 bf16x3m "A=1"
+    run_bench x3m_r5c bf16x3m "GEO4D_TWO_PASS=conv3x3,vae3x3,tconv,proj_in,ln,ff"
+    run_bench x3m_all_2 bf16x3m "A=1"
+    ;;
   r5c)         # two-pass f16 widened to tconv / proj_in / LayerNorm-fed plain-row projections / the GEGLU feed-forward (f16 o_split): correct? accurate? faster?
     ( time timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_presplit_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_gemm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gemm.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_gemm.log | tail -12
