@@ -10,9 +10,10 @@ Inputs are synthetic (seeded), weights random-init, everything resident in HBM b
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --height 576 --width 1024 --batch 4 --dtype f16          # BASELINE configs[4] on one GPU
 
-Compute mode (`--dtype`, default bf16x3): the headline number is quoted in the mode that MEETS the 1e-3 point-map parity bar
-(bf16 MFMA on a 3-term hi/lo split of f32-stored operands, geo4d_amd/precision.py); the plain-bf16 fast mode (2e-2 parity)
-is timed in the same run and reported under `fast_mode`. N > 1: window-data-parallel denoise, FRAME-SHARDED VAE decode
+Compute mode (`--dtype`, default bf16x3m): the headline number is quoted in a mode that MEETS the 1e-3 point-map parity bar - bf16x3m =
+bf16 MFMA on a 3-term hi/lo split of f32-stored operands (bf16x3), with the GEMMs fed by a normalised branch activation in two f16
+passes (geo4d_amd/precision.py; 1.1e-4 over 50 steps at BASELINE size). The all-three-pass bf16x3 mode (2e-5) and the plain-bf16 fast
+mode (2e-2: NOT the bar) are timed in the same run and reported under `strict_mode` / `fast_mode`. N > 1: window-data-parallel denoise, FRAME-SHARDED VAE decode
 (every rank decodes its frame slice of all the round's windows) and an RCCL all-gather of the decoded maps that overlaps
 the next window's denoise.
 
@@ -358,7 +359,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "bf16x3m", "bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="bf16x3m", choices=["bf16x3m", "bf16x3", "bf16", "f16", "f32"])
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=512)
@@ -370,7 +371,8 @@ def main():
                     "the barrier / max-over-ranks timing protocol on an empty step and print the JSON skeleton (tests/test_dist_cpu.py)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the plain-bf16 timing reported next to the bf16x3 headline")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the plain-bf16 timing reported next to the headline")
+    ap.add_argument("--no-strict-mode", action="store_true", help="skip the all-three-pass bf16x3 timing reported next to the bf16x3m headline")
     ap.add_argument("--no-shipped-setting", action="store_true", help="skip the extra steps at --ddim_steps 5 (the reference's shipped setting, scripts/infer_geo4d.sh:22)")
     ap.add_argument("--clip-frames", type=int, default=0, help="STRONG-scaling mode: ONE synthetic clip of this many frames end to end (sliding windows round-robin "
                     "over the ranks, frame-sharded decode, all-gather, sharded alignment) instead of one window per rank per step; 64 / 128 = BASELINE configs[2] / [3]")
@@ -509,8 +511,10 @@ def main():
                                    f"{args.ddim_steps}-step DDIM (eta 0, CFG 1, uniform_trailing, dynamic rescale) over the 1.44B-param 3D U-Net + "
                                    f"4-modality VAE decode; {cfg_name}", "windows_per_gpu_per_step": B,
                        "compute_mode": {"bf16x3": "f32 storage, every product = 3 bf16 MFMAs on a hi/lo split (meets the 1e-3 point-map parity bar)",
-                                        "bf16x3m": "bf16x3, except the long-K 3x3 convolutions (U-Net ResBlocks, VAE decoder ResnetBlocks): 2 f16 MFMAs per product on an "
-                                                   "f16 activation x an f16 hi+lo weight (meets the 1e-3 point-map parity bar: tests/test_fullsize_gpu.py, 50 steps at this size)",
+                                        "bf16x3m": "f32 storage; products in 3 bf16 MFMAs on a hi/lo split (bf16x3), except the GEMMs fed by a normalised branch activation "
+                                                   "(3x3 and temporal convolutions, LayerNorm-fed q / qkv projections, the GEGLU feed-forward, the VAE decoder's 3x3 convolutions): "
+                                                   "2 f16 MFMAs per product on an f16 activation x an f16 hi+lo weight (meets the 1e-3 point-map parity bar: 1.1e-4 over 50 steps "
+                                                   "at this size, tests/test_fullsize_gpu.py)",
                                         "bf16": "single bf16 MFMA pass, bf16 storage (fast mode, 2e-2 parity)", "f16": "single f16 MFMA pass",
                                         "f32": "exact f32 MFMA"}[args.dtype],
                        "parallelism": f"window-dp{world}" + (f" + {'frame-sharded' if decode_mode == 'sharded' else 'local'} VAE decode + "
@@ -558,6 +562,17 @@ def main():
             res["shipped_setting"] = {"ddim_steps": 5, "value": T * B * 2 * world / sdt, "unit": "frames/s", "ms_per_step": 1e3 * sdt / 2, "steps": 2,
                                       "split_ms_per_step": {"ddim_denoise": ssplit[0] / 2, "vae_decode_4_modalities": ssplit[1] / 2},
                                       "note": "scripts/infer_geo4d.sh:22 runs 5 DDIM steps: decode-bound"}
+    if not args.no_strict_mode and args.dtype == "bf16x3m":
+        # every product in three bf16 passes (round 2-4's headline mode: 2e-5 on the point map), same engine / weights / inputs, same process
+        set_mode(model, pvae, "bf16x3")
+        ssteps = max(1, min(args.steps, 3))
+        xdt, xsplit = run_mode(DDIMSampler(model, use_graph=not args.no_graph), ssteps, 1)
+        set_mode(model, pvae, args.dtype)
+        if rank == 0:
+            res["strict_mode"] = {"dtype": "bf16x3", "value": T * B * ssteps * world / xdt, "unit": "frames/s", "ms_per_step": 1e3 * xdt / ssteps, "steps": ssteps,
+                                  "split_ms_per_step": {"ddim_denoise": xsplit[0] / ssteps, "vae_decode_4_modalities": xsplit[1] / ssteps},
+                                  "parity": "point map 1.8e-5 over 50 steps at this size vs the exact-f32 engine, 2.1e-5 vs the reference (3 steps); the headline mode "
+                                            "bf16x3m: 1.1e-4 / 3.5e-4 (tests/test_fullsize_gpu.py; bar 1e-3)"}
     if not args.no_fast_mode and args.dtype in ("bf16x3", "bf16x3m"):
         # the plain-bf16 fast mode, same engine / weights / inputs, timed in the same process (all ranks take part)
         set_mode(model, pvae, "bf16")

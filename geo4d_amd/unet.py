@@ -434,16 +434,11 @@ class UNetModel(ParamTree):
             h2 = y
         return h2
 
-    def _ff(self, blk, x, e):
-        """The feed-forward. Its result feeds ONLY the transformer's proj_out: where the ff-out launch is un-split anyway (levels 0 / 1:
-        M >= 8192; a pre-split output has no split-K form) its epilogue writes the pre-split operand format proj_out multiplies (round 5:
-        proj_out used to split a raw f32 activation in its K loop)."""
+    def _ff(self, blk, x):
+        # (round 5 also tried the ff-out epilogue writing proj_out's pre-split operand: no gain in either mode, profiles/r05_two_pass_f16.md)
         sp = "f16" if blk.get("x2ff") else self.presplit      # two-pass f16 feed-forward: LayerNorm and the GEGLU epilogue write f16 halves
         g = ops.linear(ops.layernorm(x, *blk["norm3"], split_out=sp), *blk["ff1"], act=2, split_out=sp)
-        chain = False
-        if self.presplit and x.shape[0] >= 8192 and x.shape[1] % 8 == 0:
-            chain = "f16" if (blk.get("x2ff") and e.get("x2out")) else (True if not (blk.get("x2ff") or e.get("x2out")) else False)
-        return ops.linear(g, *blk["ff2"], residual=x, split_out=chain)
+        return ops.linear(g, *blk["ff2"], residual=x)
 
     def _spatial(self, e, L, h, kv, B, T, H, W):
         F_, N, C_, heads = B * T, H * W, L.inner, L.heads
@@ -472,7 +467,7 @@ class UNetModel(ParamTree):
             sets.append((k_i[:, off:off + C_], vt_i[L.prefix], 16, 1, 16))
         att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
-        x = self._ff(blk, x, e)
+        x = self._ff(blk, x)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)
 
     def _temporal(self, e, L, h, B, T, H, W):
@@ -484,7 +479,7 @@ class UNetModel(ParamTree):
             qkv = ops.linear(ops.layernorm(x, *blk[n], split_out="f16" if blk.get("x2ln") else sp), blk[a + ".qkv"])
             att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125, split_out=sp)
             x = ops.linear(att, *blk[a + ".o"], residual=x)
-        x = self._ff(blk, x, e)
+        x = self._ff(blk, x)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)
 
     def _run(self, P, layers, h, emb_all, kv, B, T, H, W):

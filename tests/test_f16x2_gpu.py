@@ -231,7 +231,7 @@ def test_geglu_feed_forward_chain_two_pass(dev, tile):
     ref = h[:, :inner] * TF.gelu(h[:, inner:])
     hi, lo = split_halves(g)
     close(f"geglu tile{tile}: hi + lo", hi + lo, ref)
-    big = (hi + lo).abs() > 1e-3          # (below the f16 normal range lo is itself a rounded subnormal: hi + lo may land one step off hi)
+    big = (hi + lo).abs() > 0.25          # (below 2^-3 the lo half is an f16 SUBNORMAL, i.e. itself rounded: hi + lo may land on a midpoint)
     assert torch.equal(hi[big].float().to(torch.float16), (hi + lo)[big].float().to(torch.float16)), "hi is not the f16 rounding of the stored value"
     y = both_grids(lambda: ops.linear(g, wp2, b2, residual=x, tile_hint=tile if tile != 27 else 25, split_k=1 if tile else 0))
     close(f"ff-out tile{tile}", y, hi @ weight_seen(wp2).t() + b2.double() + x.double())
@@ -266,30 +266,3 @@ def test_raw_f32_activation_is_converted_in_the_kernel(dev, tile):
         ref = TF.conv2d(xin, ws, bc.double(), stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
         o = both_grids(lambda: ops.conv2d(xt, wp, bc, F=F, Hin=H, Win=W, KH=3, KW=3, stride=stride, pad=1, ups=ups, gn_stats=True, **sk)[0])
         close(f"raw conv tile{tile} stride{stride} ups{ups}", o, ref)
-
-
-def test_ff_out_feeds_proj_out_pre_split(dev):
-    """Round 5: the ff-out epilogue writes the pre-split format proj_out multiplies (unet._ff `chain`), in both modes: bf16 halves from the
-    bf16x3 launch (bit-identical to the plain output multiplied as a raw activation: the split is the same arithmetic), f16 halves from
-    the two-pass launch (== the raw two-pass launch on the plain output: the same f16 values)."""
-    from geo4d_amd import ops, pack
-    M, C = 8192, 320
-    g, x, h = rnd((M, 4 * C), dev, 100), rnd((M, C), dev, 101), rnd((M, C), dev, 102)
-    w2, b2 = rnd((C, 4 * C), dev, 103, 0.03), rnd((C,), dev, 104)
-    wo, bo = rnd((C, C), dev, 105, 0.05), rnd((C,), dev, 106)
-    for mode in ("bf16x3", "bf16x3m"):
-        if mode == "bf16x3":
-            gs = ops.SplitAct.wrap(pack.split_bf16(g))
-            p2, po = pack.pack_linear(w2, "bf16x3"), pack.pack_linear(wo, "bf16x3")
-            fmt = True
-        else:
-            gs = split_f16_act(g)
-            p2, po = pack.pack_linear_x2(w2, "bf16x3m"), pack.pack_linear_x2(wo, "bf16x3m")
-            fmt = "f16"
-        plain = ops.linear(gs, p2, b2, residual=x)
-        chained = ops.linear(gs, p2, b2, residual=x, split_out=fmt)
-        hi, lo = split_halves(chained)
-        assert rel(hi + lo, plain.double()) < 1e-5, mode
-        y_plain = ops.linear(plain, po, bo, residual=h)
-        y_chain = ops.linear(chained, po, bo, residual=h)
-        assert torch.equal(y_plain, y_chain) or rel(y_chain, y_plain) < 2e-6, (mode, rel(y_chain, y_plain))

@@ -179,11 +179,12 @@ def test_ddim_mask_blending_vs_reference_golden(dev, mode, tol):
         DDIMSampler(m).sample(mask=g["mask"].to(dev), x0=None, **kw)
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("f16", 2e-2), ("bf16", 1e-1)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16x3", 1e-3), ("bf16x3m", 1e-3), ("f16", 2e-2), ("bf16", 1e-1)])
 def test_window_end_to_end_vs_oracle(dev, mode, tol):
     """One window: DDIM (S=3, eta 0, uniform_trailing) + 4-modality decode, HIP vs oracle on identical inputs.
-    North-star bar: point-map relative L2 <= 1e-3 — asserted, un-loosened, for the exact f32 mode AND for bf16x3, the mode
-    bench.py quotes its number in; f16 / bf16 are the reported fast modes."""
+    North-star bar: point-map relative L2 <= 1e-3 — asserted, un-loosened, for the exact f32 mode, for bf16x3 AND for bf16x3m, the
+    mode bench.py quotes its number in (this tiny random-weight config is its worst case: ~5e-4 here, 1.1e-4 over 50 steps at
+    BASELINE size, tests/test_fullsize_gpu.py); f16 / bf16 are the reported fast modes."""
     from geo4d_amd.pipeline import image_guided_synthesis, postprocess_window
     from geo4d_amd.vae import AutoencoderKL
     m, u, v = _diffusion(dev, mode)
