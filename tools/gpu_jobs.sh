@@ -57,6 +57,19 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5e)         # mid-round dry run of what the driver runs: the whole GPU suite, smoke, the default bench line (clip leg, strict / fast legs, CPU baseline)
+    ( time timeout 1500 python -m pytest tests -m gpu -q -x --durations=12 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|^FAILED|assert" $O/pytest.log | tail -12; grep -E "^[0-9.]+s " $O/pytest.log | head -12
+    timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -5 $O/smoke.log
+    ( time timeout 900 python bench.py --steps 3 --warmup 1 ) > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+    python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench.json") if l.startswith("{")][-1])
+print("headline", d["dtype"], round(d["value"], 3), d["split_ms_per_step"], "strict", d.get("strict_mode", {}).get("value"), "fast", d.get("fast_mode", {}).get("value"), "shipped", d.get("shipped_setting", {}).get("value"))
+print("clip", json.dumps(d.get("clip_mode"))[:1500])
+print("cpu", d.get("cpu_baseline", {}).get("value"))
+PY
+    ;;
   r5d)         # + ff-out -> proj_out pre-split chain (both modes), raw-activation two-pass (down / up / skip / VAE upsamplers): correct? accurate (smoke!)? faster?
     ( time timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_presplit_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_gemm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gemm.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_gemm.log | tail -12
