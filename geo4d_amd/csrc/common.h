@@ -222,17 +222,6 @@ __device__ __forceinline__ void store_split8(void* row_base, int group8, const f
     *(u32x4*)(g + 16) = lo;
 }
 
-// f16x2 with a RAW f32 activation (no producer in front of it that could pre-split: residual streams): 8 f32 of a row (two 16-byte
-// chunks, k ascending) -> the 8 f16 of the MFMA fragment, clamped to the f16 range
-__device__ __forceinline__ u32x4 cvt8_f16(const u32x4& c0, const u32x4& c1) {
-    float x[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
-                  __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
-    u32x4 h;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        h[j] = f32x2_to_f16x2(__builtin_amdgcn_fmed3f(x[2 * j], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(x[2 * j + 1], -65504.0f, 65504.0f));
-    return h;
-}
 // acc += a.b with a = ah + al, b = bh + bl, dropping al.bl (2^-16 x 2^-16): three dense bf16 MFMAs, fp32 accumulate
 __device__ __forceinline__ void mma_x3(f32x16& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);

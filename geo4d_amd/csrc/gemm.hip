@@ -66,11 +66,11 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     if (p.dtype != GEO4D_BF16X3 && p.dtype != GEO4D_F16X2 && (p.a_split || p.w_split)) { geo4d_set_error("conv_gemm: a_split / w_split are bf16x3 / f16x2 (dtype 3 / 4) options"); return GEO4D_EINVAL; }
     if (p.dtype == GEO4D_F16X2) {
         // two-pass f16: pre-split x pre-split operands, plain f32 rows out, second / third generation tiles (0 = a default per shape)
-        if (!p.w_split || (p.o_split != 0 && (p.o_split != 2 || !p.a_split)) || p.out_nchw || p.out_dtype != GEO4D_F32 || (p.tile_hint != 0 && p.tile_hint < 22)) {
-            geo4d_set_error("conv_gemm: f16x2 (dtype 4) needs w_split (a_split or a raw f32 activation), a row-major f32 output (o_split 0, or 2 = f16 halves), and tile hint 0 or >= 22");
+        if (!p.a_split || !p.w_split || (p.o_split != 0 && p.o_split != 2) || p.out_nchw || p.out_dtype != GEO4D_F32 || (p.tile_hint != 0 && p.tile_hint < 22)) {
+            geo4d_set_error("conv_gemm: f16x2 (dtype 4) needs a_split and w_split, a row-major f32 output (o_split 0, or 2 = f16 halves), and tile hint 0 or >= 22");
             return GEO4D_EINVAL;
         }
-        if (p.tile_hint == 0) p.tile_hint = (p.M >= 4096 && p.ups == 1) ? (p.act == 2 ? 71 : 72) : (p.M >= 4096 ? 23 : 25);      // (GEGLU: wave tiles a multiple of 64 columns wide)
+        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? (p.act == 2 ? 71 : 72) : 25;      // (GEGLU: wave tiles a multiple of 64 columns wide)      // (GEGLU: wave tiles a multiple of 64 columns wide)
         if (p.split_k == 0) p.split_k = 1;
     }
     if (p.o_split) {

@@ -542,14 +542,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         const char* abase = smem + (buf * BM + wr * WTM) * PITCH;
         const char* bbase = smem + (2 * BM + buf * BN + wc * WTN) * PITCH;
         if constexpr (IsTwoPass<T>::value) {
-            // f16x2: the weight is always pre-split; a pre-split activation's lo chunk is never read, a RAW f32 activation (HOT = 1: the
-            // residual streams no producer could split) is converted to f16 here (4 conversions per fragment where bf16x3 splits with 12)
+            // f16x2: pre-split operands only; the activation's lo chunk is never read. (Round 5 also built the form that converts a RAW f32
+            // activation in registers - residual streams: down / up samplers, skip connections, proj_out, the VAE's upsamplers - and removed
+            // it again: rounding a STREAM to f16 took the 50-step point-map drift from 1.1e-4 to 5.3e-4 for +1 % frames/s)
             u32x4 ah[MB];
 #pragma unroll
-            for (int a = 0; a < MB; ++a) {
-                ah[a] = *(const u32x4*)(abase + a * 16 * PITCH + foff[0]);
-                if (!a_split) ah[a] = cvt8_f16(ah[a], *(const u32x4*)(abase + a * 16 * PITCH + foff[1]));
-            }
+            for (int a = 0; a < MB; ++a) ah[a] = *(const u32x4*)(abase + a * 16 * PITCH + foff[0]);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const u32x4 bh = *(const u32x4*)(bbase + b * 16 * PITCH + foff[0]);
@@ -686,8 +684,7 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     }
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
     if constexpr (IsTwoPass<T>::value) {       // f16x2: pre-split x pre-split; plain f32 rows out, or (o_split = 2) the f16 pre-split format
-        if (!p.w_split || (p.o_split && (p.o_split != 2 || !p.a_split))) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes a pre-split weight; o_split 0 or 2 (f16 halves, pre-split activation)"); return GEO4D_EINVAL; }
-        if (!p.a_split) return launch_v2_kernel<T, BM, BN, WM, WN, 1>(p, splits, stream);      // raw f32 activation, converted in registers
+        if (!p.a_split || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands; o_split 0 or 2 (f16 halves)"); return GEO4D_EINVAL; }
         if (p.o_split) {
             if (o_split_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
             geo4d_set_error("conv_gemm: o_split needs no split-K, N % 8 == 0 and 32-byte aligned output rows");

@@ -552,7 +552,7 @@ template <typename T>
 int colsum_rows_v23(const geo4d_conv_gemm_t& p) {
     const int sp = p.split_k > 1 ? p.split_k : 1;
     int rows = 0;
-    if (p.tile_hint >= 71 && p.tile_hint <= 74) rows = (v3_native<T>(p, sp) && !(IsTwoPass<T>::value && !p.a_split)) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v2_effective_hint<T>(v3_fallback_hint(p.tile_hint)));
+    if (p.tile_hint >= 71 && p.tile_hint <= 74) rows = v3_native<T>(p, sp) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v2_effective_hint<T>(v3_fallback_hint(p.tile_hint)));
     else rows = v2_wave_rows(v2_effective_hint<T>(p.tile_hint));
     if (rows == 0 || !colsum_fast_ok(p, sp) || p.M % rows) return 0;
     return rows;
@@ -581,7 +581,7 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             geo4d_set_error("conv_gemm: unknown tile_hint");
             return GEO4D_EINVAL;
         }
-        if (!v3_native<T>(p, sp) || (IsTwoPass<T>::value && !p.a_split)) {      // (the two-pass type's raw-activation form lives on the second generation only)
+        if (!v3_native<T>(p, sp)) {
             geo4d_conv_gemm_t q = p;
             q.tile_hint = v3_fallback_hint(p.tile_hint);      // (every tile sums in the same order: same bits)
             return launch_v2_typed<T>(q, stream);

@@ -256,14 +256,8 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         a_split = w_split = True
         code = BF16X3
         lda, a_bs, ldw, w_bs = lda // 2, a_bs // 2, ldw // 2, w_bs // 2
-    elif w_split and is_x2_weight(w):
-        # two-pass f16 with a RAW f32 activation (residual streams: no producer in front that could pre-split): converted to f16 in the
-        # kernel's registers (second-generation tiles)
-        assert not isinstance(out, SplitAct) and out.dtype == torch.float32 and not out_nchw and ldw % 2 == 0 and w_bs % 2 == 0
-        code = F16X2
-        alpha = alpha * w._x2_alpha
-        ldw, w_bs = ldw // 2, w_bs // 2
     elif a_split or w_split:
+        assert not (is_x2_weight(w) or is_x2_weight(a)), "a pack.split_f16 weight multiplies an f16 SplitAct (the two-pass form has no raw-activation launch)"
         code = BF16X3
         if a_split:
             assert lda % 2 == 0 and a_bs % 2 == 0

@@ -316,7 +316,7 @@ class UNetModel(ParamTree):
                 emb_w.append(sd[p + ".emb_layers.1.weight"].float()); emb_b.append(sd[p + ".emb_layers.1.bias"].float())
                 e["emb"] = (off, off + L.cout); off += L.cout
                 if L.cin != L.cout:
-                    e["skip"] = ((pack.pack_linear_x2 if x2("raw") else pack.pack_linear)(sd[p + ".skip_connection.weight"], dt), f32(p + ".skip_connection.bias"))
+                    e["skip"] = (pack.pack_linear(sd[p + ".skip_connection.weight"], dt), f32(p + ".skip_connection.bias"))
                 if self.cfg["temporal_conv"]:
                     e["tc"] = []
                     e["x2t"] = x2("tconv")
@@ -328,8 +328,7 @@ class UNetModel(ParamTree):
                 e["norm"] = norm(p + ".norm")
                 e["x2in"] = x2("proj_in")
                 e["in"] = ((pack.pack_linear_x2 if e["x2in"] else pack.pack_linear)(sd[p + ".proj_in.weight"], dt), f32(p + ".proj_in.bias"))
-                e["x2out"] = x2("proj_out")
-                e["out"] = ((pack.pack_linear_x2 if e["x2out"] else pack.pack_linear)(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias"))
+                e["out"] = (pack.pack_linear(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias"))
                 e["blk"] = block(p + ".transformer_blocks.0", cross=L.kind == "spatial")
                 if L.kind == "spatial":
                     a = p + ".transformer_blocks.0.attn2"
@@ -340,9 +339,9 @@ class UNetModel(ParamTree):
                         e["wv_img"] = pack.pack_linear(sd[a + ".to_v_ip.weight"], dt)
                     e["kv"] = (kv_off, L.inner); kv_off += L.inner
             elif L.kind == "down":
-                e["w"], e["b"] = (pack.pack_conv2d_x2 if x2("raw") else pack.pack_conv2d)(sd[p + ".op.weight"], dt), f32(p + ".op.bias")
+                e["w"], e["b"] = pack.pack_conv2d(sd[p + ".op.weight"], dt), f32(p + ".op.bias")
             elif L.kind == "up":
-                e["w"], e["b"] = (pack.pack_conv2d_x2 if x2("raw") else pack.pack_conv2d)(sd[p + ".conv.weight"], dt), f32(p + ".conv.bias")
+                e["w"], e["b"] = pack.pack_conv2d(sd[p + ".conv.weight"], dt), f32(p + ".conv.bias")
             P[p] = e
         P["emb_w"], P["emb_b"] = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
         P["k_text"] = pack.pack_linear(torch.cat(k_text, 0), dt)

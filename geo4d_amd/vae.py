@@ -171,8 +171,7 @@ class AutoencoderKL(ParamTree):
                      c2=(pk(sd[p + ".conv2.weight"], dt), f32(p + ".conv2.bias")))
             e["x2"] = pk is pack.pack_conv2d_x2
             if (p + ".nin_shortcut.weight") in sd:
-                raw2 = two_pass and dt.two_pass("raw") and self.presplit        # (its activation is the raw f32 stream: converted in the kernel)
-                e["nin"] = ((pack.pack_linear_x2 if raw2 else pack.pack_linear)(sd[p + ".nin_shortcut.weight"], dt), f32(p + ".nin_shortcut.bias"))
+                e["nin"] = (pack.pack_linear(sd[p + ".nin_shortcut.weight"], dt), f32(p + ".nin_shortcut.bias"))
             return e
         for kind, p, ci, co in self.plan:
             if kind == "res":
@@ -183,8 +182,8 @@ class AutoencoderKL(ParamTree):
                                 torch.cat([sd[p + ".q.bias"], sd[p + ".k.bias"]]).float().contiguous()),
                             v=(pack.pack_linear(sd[p + ".v.weight"], dt), f32(p + ".v.bias")),
                             o=(pack.pack_linear(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias")))
-            else:    # nearest-2x upsampling convolution on the raw f32 stream
-                P[p] = ((pack.pack_conv2d_x2 if (dt.two_pass("raw") and self.presplit) else pack.pack_conv2d)(sd[p + ".weight"], dt), f32(p + ".bias"))
+            else:
+                P[p] = (pack.pack_conv2d(sd[p + ".weight"], dt), f32(p + ".bias"))
         P["head"] = (norm("decoder.norm_out"), pack.pack_conv2d(sd["decoder.conv_out.weight"], dt), f32("decoder.conv_out.bias"))
         # channel-mean head: mean_c(conv(x, W)_c + b_c) == conv(x, mean_c W_c) + mean_c b_c  (depth modality, test_geo4d.py:254-257)
         P["head_mean"] = (P["head"][0], pack.pack_conv2d(sd["decoder.conv_out.weight"].mean(0, keepdim=True), dt),

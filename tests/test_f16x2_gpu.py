@@ -238,31 +238,3 @@ def test_geglu_feed_forward_chain_two_pass(dev, tile):
     for bad in (23, 72, 73):
         with pytest.raises(RuntimeError):
             ops.linear(xs, wp, bp, act=2, split_out="f16", tile_hint=bad, split_k=1)
-
-
-@pytest.mark.parametrize("tile", [0, 23, 25, 27, 28, 72])
-def test_raw_f32_activation_is_converted_in_the_kernel(dev, tile):
-    """The two-pass form on a RAW f32 activation (residual streams: U-Net down / up samplers, skip connections, proj_out below level 1,
-    the VAE's upsampling convolutions and shortcuts): converted to f16 in the kernel's registers (second-generation tiles; a
-    third-generation hint runs on its twin). Linear + 3x3 convolutions with stride 2 and with the nearest-2x upsampling gather."""
-    from geo4d_amd import ops, pack
-    M, K, N = 1000, 320, 456
-    x, w = rnd((M, K), dev, 90), rnd((N, K), dev, 91, 0.05)
-    b, r = rnd((N,), dev, 92), rnd((M, N), dev, 93)
-    wp = pack.pack_linear_x2(w, "bf16x3m")
-    sk = dict(tile_hint=tile, split_k=1) if tile else {}
-    out = both_grids(lambda: ops.linear(x, wp, b, residual=r, **sk))
-    close(f"raw linear tile{tile}", out, a_seen(x) @ weight_seen(wp).t() + b.double() + r.double())
-    assert torch.equal(out, ops.linear(split_f16_act(x), wp, b, residual=r, **sk)), "raw activation != pre-split activation (same f16 values)"
-    F, H, W, Ci, Co = 3, 10, 8, 128, 96
-    x_nchw = rnd((F, Ci, H, W), dev, 94)
-    wc, bc = rnd((Co, Ci, 3, 3), dev, 95, 0.03), rnd((Co,), dev, 96)
-    xt = x_nchw.permute(0, 2, 3, 1).reshape(F * H * W, Ci).contiguous()
-    wp = pack.pack_conv2d_x2(wc, "bf16x3m")
-    ws = weight_seen(wp).reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
-    xa = a_seen(xt).reshape(F, H, W, Ci).permute(0, 3, 1, 2)
-    for stride, ups in ((2, 1), (1, 2), (1, 1)):
-        xin = TF.interpolate(xa, scale_factor=2, mode="nearest") if ups == 2 else xa
-        ref = TF.conv2d(xin, ws, bc.double(), stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
-        o = both_grids(lambda: ops.conv2d(xt, wp, bc, F=F, Hin=H, Win=W, KH=3, KW=3, stride=stride, pad=1, ups=ups, gn_stats=True, **sk)[0])
-        close(f"raw conv tile{tile} stride{stride} ups{ups}", o, ref)

@@ -57,6 +57,11 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5f)         # the whole GPU suite (no -x: every failure shows)
+    ( time timeout 1800 python -m pytest tests -m gpu -q --durations=12 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|^FAILED|^ERROR" $O/pytest.log | tail -20; grep -E "^[0-9.]+s " $O/pytest.log | head -12
+    grep -E "\[clip|\[full|\[3-step|\[50-step|\[window e2e\]" $O/pytest.log | cut -c1-500 | tail -12
+    ;;
   r5e)         # mid-round dry run of what the driver runs: the whole GPU suite, smoke, the default bench line (clip leg, strict / fast legs, CPU baseline)
     ( time timeout 1500 python -m pytest tests -m gpu -q -x --durations=12 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
     grep -E "passed|failed|rc=|Error|^FAILED|assert" $O/pytest.log | tail -12; grep -E "^[0-9.]+s " $O/pytest.log | head -12
