@@ -231,8 +231,8 @@ def test_geglu_feed_forward_chain_two_pass(dev, tile):
     ref = h[:, :inner] * TF.gelu(h[:, inner:])
     hi, lo = split_halves(g)
     close(f"geglu tile{tile}: hi + lo", hi + lo, ref)
-    big = (hi + lo).abs() > 0.25          # (below 2^-3 the lo half is an f16 SUBNORMAL, i.e. itself rounded: hi + lo may land on a midpoint)
-    assert torch.equal(hi[big].float().to(torch.float16), (hi + lo)[big].float().to(torch.float16)), "hi is not the f16 rounding of the stored value"
+    # hi carries the value to f16 precision on its own (what the ff-out launch multiplies): the lo half is at most half an ulp of hi
+    assert bool((lo.abs() <= hi.abs() * 2.0 ** -10 + 2.0 ** -24).all()), "lo is larger than half an f16 ulp of hi"
     y = both_grids(lambda: ops.linear(g, wp2, b2, residual=x, tile_hint=tile if tile != 27 else 25, split_k=1 if tile else 0))
     close(f"ff-out tile{tile}", y, hi @ weight_seen(wp2).t() + b2.double() + x.double())
     for bad in (23, 72, 73):

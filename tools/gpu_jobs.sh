@@ -57,6 +57,15 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5g)         # where does a bf16x3m step go now? (kernel trace of the bench split into phases) + the two-pass test file
+    ( timeout 300 python -m pytest tests/test_f16x2_gpu.py -m gpu -q ) > $O/pytest_x2.log 2>&1; tail -3 $O/pytest_x2.log
+    cd /tmp
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-shipped-setting --no-clip-leg > $O/kt.log 2>&1
+    find /tmp/prof/kt -name "*kernel_stats.csv" -exec cp {} $O/kt_kernel_stats.csv \;
+    KT=$(find /tmp/prof/kt -name "*kernel_trace.csv" | head -1)
+    [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 40 > $O/phases.md 2>&1
+    head -60 $O/phases.md | cut -c1-200
+    ;;
   r5f)         # the whole GPU suite (no -x: every failure shows)
     ( time timeout 1800 python -m pytest tests -m gpu -q --durations=12 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
     grep -E "passed|failed|rc=|^FAILED|^ERROR" $O/pytest.log | tail -20; grep -E "^[0-9.]+s " $O/pytest.log | head -12
