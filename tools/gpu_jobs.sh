@@ -57,6 +57,25 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5h)         # one-launch GroupNorm for small statistics: correct? faster? (A/B in one box: GEO4D_GN_SMALL=2 = the three-launch form everywhere)
+    ( timeout 600 python -m pytest tests/test_gn_small_gpu.py tests/test_kernels_gpu.py tests/test_bf16x3_gpu.py tests/test_parity_gpu.py -m gpu -q ) > $O/pytest.log 2>&1; tail -4 $O/pytest.log; grep -E "^FAILED|^ERROR" $O/pytest.log | head
+    timeout 200 python tools/norm_bench.py --dtype f32 > $O/norm.log 2>&1; show $O/norm.log | tail -24
+    run_bench() {   # name, dtype, extra env
+      env $3 timeout 400 python bench.py --steps 3 --warmup 1 --dtype $2 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_$1.json 2> $O/bench_$1.err
+      python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_$1.json")); r = d["roofline"]
+    print("$1:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print("$1 failed", e)
+PY
+    }
+    run_bench three_1 bf16x3m "GEO4D_GN_SMALL=2"
+    run_bench small_1 bf16x3m "A=1"
+    run_bench three_2 bf16x3m "GEO4D_GN_SMALL=2"
+    run_bench small_2 bf16x3m "A=1"
+    ;;
   r5g)         # where does a bf16x3m step go now? (kernel trace of the bench split into phases) + the two-pass test file
     ( timeout 300 python -m pytest tests/test_f16x2_gpu.py -m gpu -q ) > $O/pytest_x2.log 2>&1; tail -3 $O/pytest_x2.log
     cd /tmp

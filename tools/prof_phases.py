@@ -50,24 +50,26 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    # kernels per forward inside a replayed step
+    # kernels per forward inside a replayed step = the SHORTEST gather_timestep .. ddim_step span (the sampler's first, eager step of a
+    # process also holds the tuner's trial launches of shapes missing from the table)
     L = None
-    for i, (_, _, n) in enumerate(rows):
-        if n.startswith("gather_timestep"):
-            j = next((k for k in range(i + 1, len(rows)) if rows[k][2].startswith("ddim_step")), None)
-            if j is not None:
-                L = j - i - 1
-                break
+    gat = [i for i, r in enumerate(rows) if r[2].startswith("gather_timestep")]
+    dd = [i for i, r in enumerate(rows) if r[2].startswith("ddim_step")]
+    import bisect
+    for i in gat:
+        k = bisect.bisect_right(dd, i)
+        if k < len(dd):
+            L = dd[k] - i - 1 if L is None else min(L, dd[k] - i - 1)
     phase = [None] * len(rows)
     i, steps, eager = 0, 0, 0
     while i < len(rows):
         n = rows[i][2]
         if n.startswith("gather_timestep") and L is not None:
-            for k in range(i, min(len(rows), i + L + 3)):
-                phase[k] = "replayed DDIM step"
-                if rows[k][2].startswith("advance_index"):
-                    break
-            steps += 1
+            k = next((q for q in range(i, len(rows)) if rows[q][2].startswith("advance_index")), len(rows) - 1)
+            replay = (k - i) <= L + 3
+            for q in range(i, k + 1):
+                phase[q] = "replayed DDIM step" if replay else "eager first step of a sampler (with tuner trial launches)"
+            steps += 1 if replay else 0
             i = k + 1
             continue
         if n.startswith("timestep_embedding") and L is not None:
@@ -89,7 +91,7 @@ def main():
     print(f"# phases of `{path.split('/')[-1]}` by kernel sequence")
     print(f"{len(rows)} dispatches, {sum(tot.values()):.1f} ms of kernel time; kernels per U-Net forward inside a step: {L}; replayed DDIM steps: {steps} "
           f"(= {steps / 50:.2f} windows of 50); eager forwards: {eager}; NCTHW-head launches outside forwards: {heads} (5 per 4-modality decode -> {heads / 5:.1f} decodes)\n")
-    for ph in ("replayed DDIM step", "eager U-Net forward", "decode / encode / other library kernels", "torch (ATen) kernels"):
+    for ph in ("replayed DDIM step", "eager first step of a sampler (with tuner trial launches)", "eager U-Net forward", "decode / encode / other library kernels", "torch (ATen) kernels"):
         if ph not in tot:
             continue
         units = {"replayed DDIM step": steps, "eager U-Net forward": eager, "decode / encode / other library kernels": max(1.0, heads / 5)}.get(ph, 1) or 1
