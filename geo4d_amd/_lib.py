@@ -48,7 +48,6 @@ class GroupNorm(C.Structure):
         ("ldx", C.c_long), ("ldy", C.c_long),
         ("F", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("frames_per_stat", C.c_int),
         ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("split_out", C.c_int), ("colsum_rows", C.c_int),
-        ("small", C.c_int),
     ]
 
 

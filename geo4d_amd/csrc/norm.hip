@@ -245,91 +245,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     gn_apply_body<T, SPLIT>(x, ldx, y, ldy, HW, C, G, R, stats + (long)(f / fps) * G * 2, gamma, beta, act, blockIdx.x, f);
 }
 
-// ---- GroupNorm in ONE launch where a statistic is small (round 5) -------------------------------------------------------------------
-// One workgroup per (statistic, group): mean, then the centred sum of squares, then the apply - three reads of the group's slab, of
-// which the second and third hit L2 (the slab is <= 128 KB), one write, no workspace, no merge of partials, deterministic (fixed-order
-// wave butterflies + a fixed 4-wave sum). At the 10x16 / 5x8 / 20x32 levels of the U-Net the three-launch form costs 3 x ~7 us of launch
-// floor per GroupNorm whatever it moves (86 of the 166 GroupNorms of a forward); rounds 3-4 tried to cut launches with grid-wide
-// synchronisation on the LARGE tensors (slower: an agent-scope release per workgroup) - small statistics need none.
-__device__ __forceinline__ float block_sum_256(float v, float* red) {     // all 256 threads get the sum; fixed order
-    v = wave_sum(v);
-    __syncthreads();                                                      // (red may still be read from the previous call)
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-template <typename T, int SPLIT>
-__global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int HW, int C, int G, int fps,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act, float eps) {
-    constexpr int EPC = Elem<T>::EPC;
-    __shared__ float red[4];
-    const int tid = threadIdx.x;
-    const int stat = blockIdx.x / G, grp = blockIdx.x - stat * G;
-    const int cpg = C / G, cpr = cpg / EPC;                               // channels / 16-byte chunks of this group per row
-    const long rows = (long)fps * HW;
-    const T* xb = x + (long)stat * rows * ldx + (long)grp * cpg;
-    T* yb = y + (long)stat * rows * ldy;
-    const long items = rows * cpr;
-    const int dr = 256 / cpr, dc = 256 - dr * cpr;                        // (row, chunk) advance of a 256-item stride
-    const long r0 = tid / cpr;
-    const int c0 = tid - (int)r0 * cpr;
-    float s = 0.f;
-    {
-        long r = r0; int c = c0;
-        for (long i = tid; i < items; i += 256) {
-            float e[EPC];
-            chunk_to_f32<T>(*(const u32x4*)(xb + r * ldx + c * EPC), e);
-#pragma unroll
-            for (int j = 0; j < EPC; ++j) s += e[j];
-            r += dr; c += dc;
-            if (c >= cpr) { c -= cpr; ++r; }
-        }
-    }
-    const float n = (float)rows * (float)cpg;
-    const float mean = block_sum_256(s, red) / n;
-    float q = 0.f;
-    {
-        long r = r0; int c = c0;
-        for (long i = tid; i < items; i += 256) {
-            float e[EPC];
-            chunk_to_f32<T>(*(const u32x4*)(xb + r * ldx + c * EPC), e);
-#pragma unroll
-            for (int j = 0; j < EPC; ++j) { const float d = e[j] - mean; q += d * d; }
-            r += dr; c += dc;
-            if (c >= cpr) { c -= cpr; ++r; }
-        }
-    }
-    const float rstd = 1.0f / sqrtf(block_sum_256(q, red) / n + eps);
-    {
-        long r = r0; int c = c0;
-        for (long i = tid; i < items; i += 256) {
-            float e[EPC];
-            chunk_to_f32<T>(*(const u32x4*)(xb + r * ldx + c * EPC), e);
-            const int ch = grp * cpg + c * EPC;
-#pragma unroll
-            for (int j = 0; j < EPC; ++j) {
-                const float sc = rstd * gamma[ch + j];
-                float o = (e[j] - mean) * sc + beta[ch + j];
-                if (act == 1) o = silu_f(o);
-                e[j] = o;
-            }
-            if constexpr (SPLIT == 1) store_split4(yb + r * ldy, ch / EPC, e);
-            else if constexpr (SPLIT == 2) store_split4_f16(yb + r * ldy, ch / EPC, e);
-            else *(u32x4*)(yb + r * ldy + ch) = f32_to_chunk<T>(e);
-            r += dr; c += dc;
-            if (c >= cpr) { c -= cpr; ++r; }
-        }
-    }
-}
-// the one-launch form serves a GroupNorm when a (statistic, group) slab is at most this many bytes, the group's channels are whole
-// 16-byte chunks and there are enough units to occupy the chip's queues (a 5-D GroupNorm has only `groups` of them)
-inline bool gn_small_ok(const geo4d_groupnorm_t& p, int esz) {
-    const int cpg = p.C / p.groups, epc = 16 / esz;
-    const long unit_bytes = (long)p.frames_per_stat * p.HW * cpg * esz;
-    return p.small != 2 && (cpg % epc) == 0 && cpg / epc <= 256 && unit_bytes <= (p.small == 1 ? (1L << 40) : 128 * 1024) &&
-           ((long)(p.F / p.frames_per_stat) * p.groups >= 32 || p.small == 1);
-}
-
 // ---- LayerNorm: one wave per row, row held in registers ------------------------------------
 template <typename T, int MAXC, int SPLIT = 0>  // MAXC = chunks per lane; SPLIT (f32 only): write a pre-split operand format (1: bf16 hi | lo, 2: f16 hi | lo)
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int M, int C,
@@ -419,12 +334,6 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
     const size_t smem = (size_t)256 * 2 * EPC * 4 + (size_t)2 * p.C * 4;
     const int nstat = p.F / p.frames_per_stat;
     float* stats = part + (size_t)p.F * nchunk * p.groups * 3;
-    if (gn_small_ok(p, 16 / EPC)) {      // small statistics: one launch, one workgroup per (statistic, group)
-        hipLaunchKernelGGL((gn_small_kernel<T, SPLIT>), dim3(nstat * p.groups), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW, p.C,
-                           p.groups, p.frames_per_stat, p.gamma, p.beta, p.act, p.eps);
-        GEO4D_CHECK_LAUNCH();
-        return GEO4D_OK;
-    }
     if (p.colsum) {     // statistics already summed per block of `colsum_rows` rows by the producing GEMM's epilogue: no pass over x
         const int crows = p.colsum_rows > 0 ? p.colsum_rows : 32;
         hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nstat * p.groups), dim3(256), 0, s, p.colsum, (p.frames_per_stat * p.HW) / crows,

@@ -427,10 +427,7 @@ def batched_gemm(a, b, out, *, batch, M, N, K, a_bs, b_bs, o_bs, bias=None, bias
 _gn_ws = {}
 
 
-GN_SMALL = _env_level("GEO4D_GN_SMALL", 0)      # 0: the library decides (one launch for small statistics), 1: force one launch, 2: never (A/B)
-
-
-def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=False, out=None, split_out=False, small=None):
+def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=False, out=None, split_out=False):
     """`split_out` (f32 input of the bf16x3 mode): y is returned as a SplitAct, the pre-split A operand of the conv that follows -
     True / "bf16": bf16 hi | lo (three-pass bf16x3 consumer); "f16": f16 hi | lo (two-pass f16 consumer, pack.split_f16 weights)."""
     lib = _lib.load()
@@ -460,7 +457,6 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     rows = getattr(x, "_gn_colsum_rows", 32)
     ok = cs is not None and (frames_per_stat * HW) % rows == 0 and tuple(cs.shape) == (F * HW // rows, Cc, 2)
     p.colsum, p.colsum_rows = (cs.data_ptr(), rows) if ok else (0, 0)
-    p.small = GN_SMALL if small is None else int(small)
     _lib.check(lib.geo4d_groupnorm(C.byref(p), _stream()), "geo4d_groupnorm")
     return out
 

@@ -115,9 +115,6 @@ typedef struct geo4d_groupnorm_t {
                             8 x f16 lo], values clamped to the f16 range (f16x2 consumers, dtype 4); ldy still counts channels */
     int colsum_rows;     /* rows per `colsum` entry (what geo4d_conv_gemm_colsum_rows returned for the producing launch); 0 = 32;
                             (frames_per_stat x HW) % colsum_rows == 0 */
-    int small;           /* 0 = the library decides: a GroupNorm whose (statistic, group) slab is <= 128 KB (the 20x32 / 10x16 / 5x8 levels of
-                            the U-Net) runs as ONE launch, one workgroup per (statistic, group), statistics recomputed from x (`colsum` and
-                            the workspace are not used); 1 = force that form (tests), 2 = never (the three- / two-launch form) */
 } geo4d_groupnorm_t;
 size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat);
 int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);
