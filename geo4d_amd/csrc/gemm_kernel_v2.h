@@ -49,6 +49,14 @@ template <typename T> __device__ __forceinline__ int swz_key(int row) {
     else return p;
 }
 
+// The two-pass f16 type stages ONLY the hi chunks of its activation panel (round 5, "A64"): it never multiplies the lo halves, and the
+// cost of staging is per 1 KB LDS-DMA request (profiles/r03_gemm_v2_explore_and_ablation.md), so the A panel's rows are 64 bytes - the
+// four hi chunks of a 32-k slab - and a request covers 16 rows instead of 8: half the A-side requests, same arithmetic, same bits.
+// LDS slot of K-group g in panel row r = g ^ swz_key_a64(r); ds_read_b128 service groups (see swz_key): with 4 slots per row the 16
+// lanes of a group hit 16 distinct 16-byte bank groups when rows {0-3, 4-7, 8-11, 12-15} of a 16-row block are keyed {0, 3, 2, 1}.
+__device__ __forceinline__ int swz_key_a64(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+constexpr int PITCH_A64 = 64;
+
 // ---- register epilogue shared by the second- and third-generation kernels: acc[a][b][j] is out[m_w0 + 16a + lr][n_w0 + 16b + 4lq + j]
 // (bias / row-bias / activation / GEGLU / residual / rounding in registers, 16-byte (f32) or 8-byte (16-bit) stores). `partial`:
 // split-K launch, the raw fp32 slab of split e_kz goes to the workspace and the epilogue runs in splitk_reduce_kernel.
@@ -411,7 +419,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
     constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
     constexpr int MB = WTM / 16, NB = WTN / 16;       // 16x16 accumulator blocks per wave
     constexpr int RSTEP = NT / 8;                     // panel rows covered by one staging pass of the workgroup
-    constexpr int ACH = (BM + RSTEP - 1) / RSTEP, BCH = (BN + RSTEP - 1) / RSTEP;
+    constexpr bool A64 = IsTwoPass<T>::value;         // activation panel rows = the 4 hi chunks of the slab (64 bytes): 16 rows per 1 KB request
+    constexpr int RSTEP_A = A64 ? NT / 4 : RSTEP;
+    constexpr int ACH = (BM + RSTEP_A - 1) / RSTEP_A, BCH = (BN + RSTEP - 1) / RSTEP;
     constexpr int RING = (2 * BM + 2 * BN) * PITCH;
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && BM % 8 == 0 && BN % 8 == 0, "wave tiles are multiples of 16");
     static_assert(!std::is_same<T, float>::value, "v2 serves the 16-bit MFMA forms (bf16, bf16x3)");
@@ -432,6 +442,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
     const T* __restrict__ Z = (const T*)p.zeros;
     const int ccol = tid & 7;
     const int r0 = tid >> 3;
+    const int r0a = A64 ? (tid >> 2) : r0;            // this lane's A-panel row inside a staging pass
 
     // ---- state of the tile being staged (the NEXT tile while the current one is in its epilogue) ---------------------------------
     int tm = 0, tn = 0, kz = 0, nslab = 0, tap = 0, c0 = 0, tapB = 0, c0B = 0;   // (tap, c0): A-panel cursor; (tapB, c0B): B-panel cursor
@@ -441,14 +452,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
     const T* wptr[BCH];
     int cA[ACH], cB[BCH];                              // source-side swizzle: LDS slot `ccol` of panel row r holds chunk ccol ^ key(r)
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) cA[i] = (ccol ^ swz_key<T>(r0 + i * RSTEP)) * EPC;
+    for (int i = 0; i < ACH; ++i)
+        cA[i] = A64 ? ((tid & 3) ^ swz_key_a64(r0a + i * RSTEP_A)) * 2 * EPC      // K-group g: its hi chunk sits 32 bytes (8 elements) apart
+                    : (ccol ^ swz_key<T>(r0 + i * RSTEP)) * EPC;
 #pragma unroll
     for (int i = 0; i < BCH; ++i) cB[i] = (ccol ^ swz_key<T>(r0 + i * RSTEP)) * EPC;
 
     auto fetch_pix = [&]() {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            const int row = r0 + i * RSTEP;
+            const int row = r0a + i * RSTEP_A;
             if (direct_rows) {
                 const int m = tm * BM + row;
                 pix[i] = (row < BM && m < p.M) ? m : -1;
@@ -505,7 +518,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         char* base = smem + ab * BM * PITCH + wave * 1024;
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
-            if ((ACH * RSTEP == BM) || (wave * 8 + j * RSTEP < BM)) {
+            // (A64: a wave's request covers 16 rows of 64 bytes - the same 1 KB at the same byte offsets, RSTEP * PITCH == RSTEP_A * 64)
+            if ((ACH * RSTEP_A == BM) || (wave * (A64 ? 16 : 8) + j * RSTEP_A < BM)) {
                 const T* src = pix[j] >= 0 ? A + (long)pix[j] * p.lda + c0 + cA[j] : Z;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(base + j * RSTEP * PITCH), 16, 0, 0);
@@ -542,12 +556,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         const char* abase = smem + (buf * BM + wr * WTM) * PITCH;
         const char* bbase = smem + (2 * BM + buf * BN + wc * WTN) * PITCH;
         if constexpr (IsTwoPass<T>::value) {
-            // f16x2: pre-split operands only; the activation's lo chunk is never read. (Round 5 also built the form that converts a RAW f32
+            // f16x2: pre-split operands only; the activation panel holds hi chunks only (A64). (Round 5 also built the form that converts a RAW f32
             // activation in registers - residual streams: down / up samplers, skip connections, proj_out, the VAE's upsamplers - and removed
             // it again: rounding a STREAM to f16 took the 50-step point-map drift from 1.1e-4 to 5.3e-4 for +1 % frames/s)
             u32x4 ah[MB];
+            const char* abase64 = smem + buf * BM * PITCH + (wr * WTM) * PITCH_A64 + lr * PITCH_A64 + ((lq ^ swz_key_a64(lr)) << 4);
 #pragma unroll
-            for (int a = 0; a < MB; ++a) ah[a] = *(const u32x4*)(abase + a * 16 * PITCH + foff[0]);
+            for (int a = 0; a < MB; ++a) ah[a] = *(const u32x4*)(abase64 + a * 16 * PITCH_A64);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const u32x4 bh = *(const u32x4*)(bbase + b * 16 * PITCH + foff[0]);

@@ -61,12 +61,16 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     constexpr int MB0 = (MB + 1) / 2, MB1 = MB - MB0, NB0 = (NB + 1) / 2, NB1 = NB - NB0;     // 16-blocks of R0 | R1, C0 | C1
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && MB1 >= 1 && NB1 >= 1, "wave tiles of at least 32 x 32");
     constexpr int RA0 = WM * MB0 * 16, RA1 = WM * MB1 * 16, RB0 = WN * NB0 * 16, RB1 = WN * NB1 * 16;   // rows of the half panels
-    constexpr int OA0 = 0, OA1 = RA0 * PITCH, OB0 = BM * PITCH, OB1 = (BM + RB0) * PITCH;               // their offsets in a stage
+    // A64 (the two-pass f16 type, gemm_kernel_v2.h swz_key_a64): the activation panel holds only the hi chunks - rows of 64 bytes, 16 rows
+    // per 1 KB request, 128 rows per staging pass of the 8 waves: half the A-side LDS-DMA requests of a slab
+    constexpr bool A64 = IsTwoPass<T>::value;
+    constexpr int PITCH_A = A64 ? PITCH_A64 : PITCH, RPA = A64 ? 128 : 64, RWA = A64 ? 16 : 8;          // A row pitch, rows per pass, rows per wave request
+    constexpr int OA0 = 0, OA1 = RA0 * PITCH_A, OB0 = BM * PITCH, OB1 = (BM + RB0) * PITCH;             // their offsets in a stage
     constexpr int STAGE = (BM + BN) * PITCH;
-    constexpr int PA0 = (RA0 + 63) / 64, PA1 = (RA1 + 63) / 64, PB0 = (RB0 + 63) / 64, PB1 = (RB1 + 63) / 64;   // 64-row staging passes
+    constexpr int PA0 = (RA0 + RPA - 1) / RPA, PA1 = (RA1 + RPA - 1) / RPA, PB0 = (RB0 + 63) / 64, PB1 = (RB1 + 63) / 64;   // staging passes
     // pieces EVERY wave issues per slab (ragged last passes are issued by the first waves only): the counted wait. A wave that
     // issued more has more than NWAIT younger pieces outstanding, for which vmcnt(NWAIT) is the stricter wait.
-    constexpr int CA0 = RA0 / 64, CA1 = RA1 / 64, CB0 = RB0 / 64, CB1 = RB1 / 64;
+    constexpr int CA0 = RA0 / RPA, CA1 = RA1 / RPA, CB0 = RB0 / 64, CB1 = RB1 / 64;
     constexpr int NWAIT = CA0 + CA1 + CB0 + CB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     const int ns = p.K / BK / splits;                  // slabs per tile: the host guarantees an even split, ns even and >= 4
     const int ccol = tid & 7;
     const int r0 = tid >> 3;
+    const int r0a = A64 ? (tid >> 2) : r0;             // this lane's row inside an A staging pass
 
     // ---- staging side -----------------------------------------------------------------------------------------------------------------
     // Every LDS-DMA piece is a `buffer_load_dwordx4 ... lds` on a raw buffer resource (base + 2 GB window in SGPRs): the per-lane part
@@ -94,9 +99,11 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     constexpr unsigned OOB = 0x80000000u;              // = num_records of both resources
     constexpr int ESZ = 16 / EPC;                      // bytes per element (bf16x3 stores f32)
     auto tile_row = [&](int r, int rows, int per_wave, int wt, int off) { return r < rows ? (r / per_wave) * wt + off + r % per_wave : -1; };
-    auto rowA = [&](int h, int j) { return h ? tile_row(r0 + 64 * j, RA1, MB1 * 16, WTM, MB0 * 16) : tile_row(r0 + 64 * j, RA0, MB0 * 16, WTM, 0); };
+    auto rowA = [&](int h, int j) { return h ? tile_row(r0a + RPA * j, RA1, MB1 * 16, WTM, MB0 * 16) : tile_row(r0a + RPA * j, RA0, MB0 * 16, WTM, 0); };
     auto rowB = [&](int h, int j) { return h ? tile_row(r0 + 64 * j, RB1, NB1 * 16, WTN, NB0 * 16) : tile_row(r0 + 64 * j, RB0, NB0 * 16, WTN, 0); };
     auto chunk = [&](int j) { return (ccol ^ swz_key<T>(r0 + 64 * j)) * EPC; };   // LDS slot `ccol` of panel row r holds chunk ccol ^ key(r)
+    // A64: slot (tid & 3) of panel row r holds the hi chunk of K-group slot ^ key_a64(r); a group's hi chunk sits 32 bytes = 2 EPC elements apart
+    auto chunkA = [&](int j) { return A64 ? ((tid & 3) ^ swz_key_a64(r0a + RPA * j)) * 2 * EPC : chunk(j); };
     const int khw = p.KH * p.KW;
 
     // staging cursors (two slabs ahead of the MFMAs, across tiles) and the tile they are in
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
                     const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
                     const int iy0 = oy * p.stride - p.ph, ix0 = ox * p.stride - p.pw, ft = (f % p.T) - p.pt;
                     const long px0 = ((long)(f - p.pt) * p.Hin + iy0) * p.Win + ix0;
-                    off = (unsigned)(((px0 - P0) * p.lda + chunk(j)) * ESZ);
+                    off = (unsigned)(((px0 - P0) * p.lda + chunkA(j)) * ESZ);
                     unsigned bit = 1;
                     for (int kt = 0; kt < p.KT; ++kt)
                         for (int ky = 0; ky < p.KH; ++ky)
@@ -217,9 +224,9 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         char* base = smem + st * STAGE + (H ? OA1 : OA0) + wave * 1024;
 #pragma unroll
         for (int j = 0; j < (H ? PA1 : PA0); ++j) {
-            if ((j + 1) * 64 <= R || wave * 8 + j * 64 < R) {
+            if ((j + 1) * RPA <= R || wave * RWA + j * RPA < R) {
                 const unsigned v = ((maskA[H][j] >> bitA) & 1u) ? voffA[H][j] : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + j * 64 * PITCH), 16, (int)v, (int)soffA, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + j * RPA * PITCH_A), 16, (int)v, (int)soffA, 0, 0);
             }
         }
     };
@@ -269,16 +276,21 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         foff[0] = lr * PITCH + ((lq ^ fkey) << 4);
         foff[1] = lr * PITCH + (((4 + lq) ^ fkey) << 4);
     }
+    const int foffA = lr * PITCH_A64 + ((lq ^ swz_key_a64(lr)) << 4);
     const bool a_split = HOT ? (HOT == 2) : (p.a_split != 0), w_split = HOT ? true : (p.w_split != 0);
     u32x4 fa[2][2][MB0];                               // A fragments [half][bf16x3: hi | lo; 16-bit: K half][block]: every half panel has its own
     u32x4 fb[2][2][NB0];                               // registers, so that a phase can read the set the NEXT phase multiplies
     auto read_A = [&](auto hc, const char* sb) {
         constexpr int H = decltype(hc)::value;
-        const char* base = sb + (H ? OA1 : OA0) + wr * ((H ? MB1 : MB0) * 16) * PITCH;
+        const char* base = sb + (H ? OA1 : OA0) + wr * ((H ? MB1 : MB0) * 16) * PITCH_A;
 #pragma unroll
         for (int a = 0; a < (H ? MB1 : MB0); ++a) {
-            fa[H][0][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[0]);
-            if constexpr (!IsTwoPass<T>::value) fa[H][1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);     // (f16x2 never multiplies the activation's lo half)
+            if constexpr (A64) {                     // hi chunks only: slot of K-group lq in row lr
+                fa[H][0][a] = *(const u32x4*)(base + a * 16 * PITCH_A + foffA);
+            } else {
+                fa[H][0][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[0]);
+                fa[H][1][a] = *(const u32x4*)(base + a * 16 * PITCH + foff[1]);
+            }
         }
     };
     auto read_B = [&](auto hc, const char* sb) {

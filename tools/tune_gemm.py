@@ -18,6 +18,12 @@ def main():
     dev = torch.device("cuda:0")
     old = dict(ops._tune_table())
     keep = "--keep" in sys.argv          # --keep: only shapes MISSING from the table are measured (a new mode's launches), the rest keep their entry
+    drop = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--drop-prefix=")]      # with --keep: forget the entries whose key starts with this (e.g. 4/ = the two-pass f16 launches) so that they are re-measured
+    sys.argv = [a for a in sys.argv if not a.startswith("--drop-prefix=")]
+    for pre in drop:
+        for k in [k for k in ops._tune_table() if k.startswith(pre)]:
+            del ops._tune_table()[k]
+            old.pop(k, None)
     if keep:
         sys.argv.remove("--keep")
     else:
