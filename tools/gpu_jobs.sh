@@ -57,6 +57,37 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5j)         # the 320x160 two-pass tile (hint 75): same bits? does the tuner take it? end to end?
+    ( timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q ) > $O/pytest_x2.log 2>&1; tail -3 $O/pytest_x2.log; grep -E "^FAILED|^ERROR" $O/pytest_x2.log | head
+    timeout 600 python tools/gemm_bench.py --dtype f16x2 --iters 10 --filter L0 --tiles 72,75,73,74,23 > $O/census_l0.log 2>&1; show $O/census_l0.log | tail -20
+    timeout 600 python tools/gemm_bench.py --dtype f16x2 --iters 10 --filter VAE --tiles 71,73,75 > $O/census_vae.log 2>&1; show $O/census_vae.log | tail -10
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_before.json
+    timeout 900 python tools/tune_gemm.py $O/gfx950.json --keep --drop-prefix=4/ bf16x3m > $O/tune.log 2>&1; show $O/tune.log | tail -3
+    run_bench() {   # name, dtype, extra env
+      env $3 timeout 400 python bench.py --steps 3 --warmup 1 --dtype $2 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_$1.json 2> $O/bench_$1.err
+      python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_$1.json")); r = d["roofline"]
+    print("$1:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "issued", round(r["frac_issued"], 3), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print("$1 failed", e)
+PY
+    }
+    run_bench old_table_1 bf16x3m "A=1"
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_old.json
+    [ -s $O/gfx950.json ] && cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    run_bench new_table_1 bf16x3m "A=1"
+    cp $O/gfx950_old.json geo4d_amd/tuning/gfx950.json
+    run_bench old_table_2 bf16x3m "A=1"
+    cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+    run_bench new_table_2 bf16x3m "A=1"
+    python - <<PY
+import json
+a, b = json.load(open("$O/gfx950_old.json")), json.load(open("$O/gfx950.json"))
+print("entries taking tile 75:", sum(1 for k, v in b.items() if v[0] == 75), [k for k, v in b.items() if v[0] == 75][:12])
+PY
+    ;;
   r5i)         # A64: the two-pass kernels stage only the activation's hi chunks (64-byte A rows, half the A-side requests): same bits? faster?
     ( timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q ) > $O/pytest_x2.log 2>&1; tail -3 $O/pytest_x2.log; grep -E "^FAILED|^ERROR" $O/pytest_x2.log | head
     timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; grep bf16x3m $O/smoke.log
