@@ -535,11 +535,8 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 // (256x256 does not fit: 128 accumulators + the four fragment sets of the prefetching walk spill)
 // Launches the phased stream cannot take (an odd number or fewer than 4 K slabs per tile, an uneven split-K, outputs that are not 4-element aligned,
 // nearest-upsampling gathers, operands beyond the 2 GB buffer window) fall back to the second-generation tile of the same shape.
-//   75 (round 5, the two-pass f16 type; other types run it as 72): 320x160 on 4 x 2 waves (80x80 wave tiles). With 64-byte activation rows
-//   (A64) a panel row of A costs half a weight row's staging requests, so the cheap side should be the long one: 20 + 20 requests per slab
-//   where 160x320 issues 10 + 40, for the same 51200 outputs - the N = 320 launches of level 0 (3x3 / temporal convs, ff-out).
-inline int v3_wave_rows(int hint) { return hint == 71 ? 96 : (hint == 72 || hint == 75) ? 80 : hint == 73 ? 128 : 64; }
-inline int v3_fallback_hint(int hint) { return hint == 71 ? 22 : (hint == 72 || hint == 75) ? 23 : 25; }
+inline int v3_wave_rows(int hint) { return hint == 71 ? 96 : hint == 72 ? 80 : hint == 73 ? 128 : 64; }
+inline int v3_fallback_hint(int hint) { return hint == 71 ? 22 : hint == 72 ? 23 : 25; }
 // does the phased stream take this launch (else its second-generation twin does)?
 template <typename T>
 bool v3_native(const geo4d_conv_gemm_t& p, int sp) {
@@ -558,7 +555,7 @@ bool v3_native(const geo4d_conv_gemm_t& p, int sp) {
     // the staging side addresses each operand through a 2 GB buffer window per tile (see the kernel): nearest-upsampling gathers have
     // no uniform tap offsets, and a tile's rows plus its taps must stay inside the window
     const long esz = 16 / Elem<T>::EPC;
-    const long frames = 320 / ((long)p.Hout * p.Wout) + 2 + p.KT;
+    const long frames = 256 / ((long)p.Hout * p.Wout) + 2 + p.KT;
     const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
     return !(nslab % sp || ((nslab / sp) & 1) || nslab / sp < 4 || !vec_ok || !window_ok);
 }
@@ -567,7 +564,7 @@ template <typename T>
 int colsum_rows_v23(const geo4d_conv_gemm_t& p) {
     const int sp = p.split_k > 1 ? p.split_k : 1;
     int rows = 0;
-    if (p.tile_hint >= 71 && p.tile_hint <= 75) rows = v3_native<T>(p, sp) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v2_effective_hint<T>(v3_fallback_hint(p.tile_hint)));
+    if (p.tile_hint >= 71 && p.tile_hint <= 74) rows = v3_native<T>(p, sp) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v2_effective_hint<T>(v3_fallback_hint(p.tile_hint)));
     else rows = v2_wave_rows(v2_effective_hint<T>(p.tile_hint));
     if (rows == 0 || !colsum_fast_ok(p, sp) || p.M % rows) return 0;
     return rows;
@@ -592,7 +589,7 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             }
             sp = p.split_k;
         }
-        if (p.tile_hint < 71 || p.tile_hint > 75) {
+        if (p.tile_hint < 71 || p.tile_hint > 74) {
             geo4d_set_error("conv_gemm: unknown tile_hint");
             return GEO4D_EINVAL;
         }
@@ -610,9 +607,6 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             case 72: return launch_v3_cfg<T, 160, 320, 2, 4>(p, sp, stream);
             case 73: return launch_v3_cfg<T, 256, 128, 2, 4>(p, sp, stream);
             case 74: return launch_v3_cfg<T, 128, 256, 2, 4>(p, sp, stream);
-            case 75:
-                if constexpr (IsTwoPass<T>::value) return launch_v3_cfg<T, 320, 160, 4, 2>(p, sp, stream);
-                else return launch_v3_cfg<T, 160, 320, 2, 4>(p, sp, stream);
         }
         return GEO4D_EINVAL;
     }

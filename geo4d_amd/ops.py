@@ -136,7 +136,6 @@ _CANDIDATES = [(1, 1), (2, 1), (3, 1), (4, 1), (11, 1), (13, 1), (16, 1), (17, 1
                # third generation (gemm_kernel_v3.h: phased K loop, counted DMA waits; 8-wave tiles, one workgroup per CU).
                # Splits that do not divide the K slabs evenly run on the second-generation twin inside the library.
                (71, 1), (72, 1), (73, 1), (74, 1), (71, 2), (72, 2), (73, 2), (74, 2), (71, 3), (72, 3), (73, 3), (74, 3), (71, 4), (73, 4), (74, 4),
-               (75, 1), (75, 2), (75, 3),      # 320x160 (round 5: the two-pass f16 type's twin of 72; other types run it as 72)
                (71, 5), (73, 5), (74, 5), (73, 6), (74, 6), (73, 8), (74, 8), (73, 10), (74, 10)]
 _VALID_HINTS = {t for t, _ in _CANDIDATES} | {0}
 AUTOTUNE = _os.environ.get("GEO4D_AUTOTUNE", "1") != "0"

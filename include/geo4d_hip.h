@@ -68,7 +68,7 @@ typedef struct geo4d_conv_gemm_t {
                             tiles), 25 = 128x128, 27 = 64x128, 28 = 64x64 (4 waves); GEGLU on 22, 25, 27. Third generation: the
                             same MFMA form and epilogue under a PHASED K loop (4 phases per slab, counted LDS-DMA waits, the
                             staging cursor two slabs ahead across tiles; 8 waves, one workgroup per CU): 71 = 192x256,
-                            72 = 160x320, 73 = 256x128, 74 = 128x256, 75 = 320x160 (dtype 4; other types run 72); GEGLU on 71, 74; launches with an odd number or fewer
+                            72 = 160x320, 73 = 256x128, 74 = 128x256; GEGLU on 71, 74; launches with an odd number or fewer
                             than 4 K slabs per tile, an uneven split-K or outputs that are not 4-element aligned run on
                             22 / 23 / 25 / 25 instead (same bits: every tile sums in the same order).
                             Others (incl. the hints retired in round 4: 12, 14, 21, 24, 26, 29, 31..39): -EINVAL */
