@@ -57,6 +57,26 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5k)         # same-box A/B of A64: the pre-A64 library + its table (build_b/, built in the container from commit 0f96093) against HEAD, interleaved
+    run_bench() {   # name, extra env
+      env $2 timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_$1.json 2> $O/bench_$1.err
+      python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_$1.json")); r = d["roofline"]
+    print("$1:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print("$1 failed", e)
+PY
+    }
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_head.json
+    for i in 1 2; do
+      cp build_b/gfx950_pre_a64.json geo4d_amd/tuning/gfx950.json
+      run_bench pre_a64_$i "GEO4D_HIP_LIB=$R/build_b/libgeo4d_hip_pre_a64.so"
+      cp $O/gfx950_head.json geo4d_amd/tuning/gfx950.json
+      run_bench head_$i "A=1"
+    done
+    ;;
   r5j)         # the 320x160 two-pass tile (hint 75): same bits? does the tuner take it? end to end?
     ( timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q ) > $O/pytest_x2.log 2>&1; tail -3 $O/pytest_x2.log; grep -E "^FAILED|^ERROR" $O/pytest_x2.log | head
     timeout 600 python tools/gemm_bench.py --dtype f16x2 --iters 10 --filter L0 --tiles 72,75,73,74,23 > $O/census_l0.log 2>&1; show $O/census_l0.log | tail -20
