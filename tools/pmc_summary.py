@@ -24,6 +24,15 @@ def short(name):
     return s[:70]
 
 
+def klass(n):
+    """Kernel class of a short kernel name (the classes of tools/prof_phases.py)."""
+    for pre, c in (("conv_gemm_v3", "conv_gemm third generation"), ("conv_gemm_v2", "conv_gemm second generation"), ("conv_gemm_kernel", "conv_gemm first generation"),
+                   ("splitk_reduce", "split-K reduce"), ("gn_", "GroupNorm"), ("ln_kernel", "LayerNorm"), ("flash_attn", "attention"), ("temporal_attn", "attention")):
+        if n.startswith(pre):
+            return c
+    return "other"
+
+
 def main():
     out_md, out_json, files = sys.argv[1], sys.argv[2], sys.argv[3:]
     per = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum
@@ -61,9 +70,14 @@ def main():
         lines.append(f"| `{k}` | {len(calls[k])} | {gb(2 * d.get('FETCH_SIZE', 0)):.2f} | {gb(d.get('WRITE_SIZE', 0)):.2f} | {100 * busy(d):.1f} % |")
     lines.append(f"| **whole forward** | {sum(len(v) for v in calls.values())} | **{gb(2 * tot.get('FETCH_SIZE', 0)):.1f}** | "
                  f"**{gb(tot.get('WRITE_SIZE', 0)):.1f}** | **{100 * busy(tot):.1f} %** |")
+    by_class = defaultdict(float)
+    for k, d in per.items():
+        by_class[klass(k)] += gb(2 * d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0))
+    lines += ["", "| kernel class | GB per forward (2 x fetch + write) |", "|---|---|"] + [f"| {c} | {v:.1f} |" for c, v in sorted(by_class.items(), key=lambda kv: -kv[1])]
     open(out_md, "w").write("\n".join(lines) + "\n")
     json.dump({"per_unet_forward": {"fetch_bytes_x2": 2 * tot.get("FETCH_SIZE", 0) * 1024, "write_bytes": tot.get("WRITE_SIZE", 0) * 1024,
-                                    "mfma_pipe_busy_frac": busy(tot), "dispatches": sum(len(v) for v in calls.values())},
+                                    "mfma_pipe_busy_frac": busy(tot), "dispatches": sum(len(v) for v in calls.values()),
+                                    "by_class": {c: round(v, 2) for c, v in by_class.items()}},
                "source": out_md}, open(out_json, "w"), indent=1)
     print("\n".join(lines))
 
