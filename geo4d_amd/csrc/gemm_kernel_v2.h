@@ -49,6 +49,30 @@ template <typename T> __device__ __forceinline__ int swz_key(int row) {
     else return p;
 }
 
+// Tile order inside one (batch, split) slab of tiles_m x tiles_n tiles (round 5). The persistent workgroups of an XCD work on ~32
+// CONSECUTIVE tile ids at a time (xcd_remap): with the N index fastest those are 1 row-tile x 32 column-tiles - one A panel shared, 32
+// weight panels streamed, and every row-tile streams the whole weight matrix again (PMC: the level-2 GEGLU launch fetched 14 x its 52 MB
+// weight, profiles/r05_head_pmc_bf16x3m.md). Grouped order (GROUP_M row-tiles fastest inside a band of GROUP_M rows) makes them a
+// GROUP_M x 32 / GROUP_M block: every panel staged by a workgroup is being staged by GROUP_M - 1 (weights) or 32 / GROUP_M - 1
+// (activations) others of the same L2 at about the same time. Same tiles, same arithmetic: bits unchanged.
+__device__ __forceinline__ void tile_of(long t, int tiles_n, int tiles_mn, int group_m, int& tm, int& tn) {
+    const int tiles_m = tiles_mn / tiles_n;
+    if (group_m <= 1 || tiles_n < 2 || tiles_m < 2) {
+        tm = (int)(t / tiles_n);
+        tn = (int)(t - (long)tm * tiles_n);
+        return;
+    }
+    const int per_band = group_m * tiles_n;
+    const int band = (int)(t / per_band);
+    const int first_m = band * group_m;
+    const int rows = min(tiles_m - first_m, group_m);
+    const int r = (int)(t - (long)band * per_band);
+    tn = r / rows;
+    tm = first_m + (r - tn * rows);
+}
+// debug_ablate 16 + g (A/B runs, tests): force GROUP_M = g (17 = the N-fastest order of rounds 1-4); otherwise 4
+__device__ __forceinline__ int tile_group_m(const geo4d_conv_gemm_t& p) { return (p.debug_ablate >= 16 && p.debug_ablate < 48) ? p.debug_ablate - 16 : 4; }
+
 // The two-pass f16 type stages ONLY the hi chunks of its activation panel (round 5, "A64"): it never multiplies the lo halves, and the
 // cost of staging is per 1 KB LDS-DMA request (profiles/r03_gemm_v2_explore_and_ablation.md), so the A panel's rows are 64 bytes - the
 // four hi chunks of a 32-k slab - and a request covers 16 rows instead of 8: half the A-side requests, same arithmetic, same bits.
@@ -474,8 +498,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         const long t = w % tiles_mn, rest = w / tiles_mn;
         bz = rest % p.batch;
         kz = (int)(rest / p.batch);
-        tm = (int)(t / tiles_n);
-        tn = (int)(t - (long)tm * tiles_n);
+        tile_of(t, tiles_n, tiles_mn, tile_group_m(p), tm, tn);
         A = (const T*)p.A + bz * p.a_bs;
         const T* __restrict__ W = (const T*)p.W + bz * p.w_bs;
 #pragma unroll

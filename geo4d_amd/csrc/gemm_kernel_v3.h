@@ -202,8 +202,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
         const long t = w_ % tiles_mn, rest = w_ / tiles_mn;
         bzS = rest % p.batch;
         kzS = (int)(rest / p.batch);
-        tmS = (int)(t / tiles_n);
-        tnS = (int)(t - (long)tmS * tiles_n);
+        tile_of(t, tiles_n, tiles_mn, tile_group_m(p), tmS, tnS);
         rB = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + bzS * p.w_bs + (long)tnS * BN * p.ldw), 0, OOB, 0x00020000);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
