@@ -156,9 +156,8 @@ def _env_level(name, default):
 
 
 GN_FUSED_STATS = _env_level("GEO4D_GN_FUSED", 1)
-DEBUG_ABLATE = _env_level("GEO4D_DEBUG_ABLATE", 0)
 TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) of every shape autotuned in this process (tools/tune_gemm.py prints it)
-DEBUG_ABLATE = 0       # tests / A-B runs: 2 = three persistent workgroups; 16 + g = tile order with GROUP_M = g (17 = N-fastest); $GEO4D_DEBUG_ABLATE sets it below
+DEBUG_ABLATE = _env_level("GEO4D_DEBUG_ABLATE", 0)       # tests / A-B runs: 2 = three persistent workgroups; 16 + g = tile order with GROUP_M = g (17 = column-fastest)
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end, MFMA passes per product)
 ATTN_TIMELINE = None   # the same for the spatial self-attention launches (one key/value set) of ops.attention
 

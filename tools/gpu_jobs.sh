@@ -57,6 +57,31 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5m)         # r5l's A/B again with the switch actually reaching the library (bench only + the column-fastest PMC passes)
+    run_bench() {   # name, extra env
+      env $2 timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-shipped-setting > $O/bench_$1.json 2> $O/bench_$1.err
+      python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_$1.json")); r = d["roofline"]
+    print("$1:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2))
+except Exception as e:
+    print("$1 failed", e)
+PY
+    }
+    for i in 1 2; do
+      run_bench ncol_$i "GEO4D_DEBUG_ABLATE=17"
+      run_bench group4_$i "A=1"
+    done
+    cd /tmp
+    i=0
+    for c in "FETCH_SIZE" "WRITE_SIZE"; do
+      i=$((i+1))
+      GEO4D_DEBUG_ABLATE=17 timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof/pmc_17_$i -o p -- python $R/tools/profile_unet.py 1 bf16x3m > $O/pmc_17_$i.log 2>&1
+    done
+    python $R/tools/pmc_summary.py $O/pmc_17.md $O/pmc_17.json $(find /tmp/prof/pmc_17_1 /tmp/prof/pmc_17_2 -name "*counter_collection.csv") > $O/pmc_summary_17.log 2>&1
+    grep "whole forward" $O/pmc_17.md; tail -9 $O/pmc_17.md
+    ;;
   r5l)         # grouped tile order (GROUP_M = 4) against the column-fastest order of rounds 1-4 (GEO4D_DEBUG_ABLATE=17), same library, same box: bits? frames/s? L2-miss traffic?
     ( timeout 600 python -m pytest tests/test_f16x2_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_presplit_gpu.py -m gpu -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log; grep -E "^FAILED|^ERROR" $O/pytest.log | head
     run_bench() {   # name, extra env
