@@ -49,12 +49,14 @@ template <typename T> __device__ __forceinline__ int swz_key(int row) {
     else return p;
 }
 
-// Tile order inside one (batch, split) slab of tiles_m x tiles_n tiles (round 5). The persistent workgroups of an XCD work on ~32
-// CONSECUTIVE tile ids at a time (xcd_remap): with the N index fastest those are 1 row-tile x 32 column-tiles - one A panel shared, 32
-// weight panels streamed, and every row-tile streams the whole weight matrix again (PMC: the level-2 GEGLU launch fetched 14 x its 52 MB
-// weight, profiles/r05_head_pmc_bf16x3m.md). Grouped order (GROUP_M row-tiles fastest inside a band of GROUP_M rows) makes them a
-// GROUP_M x 32 / GROUP_M block: every panel staged by a workgroup is being staged by GROUP_M - 1 (weights) or 32 / GROUP_M - 1
-// (activations) others of the same L2 at about the same time. Same tiles, same arithmetic: bits unchanged.
+// Tile order inside one (batch, split) slab of tiles_m x tiles_n tiles. The persistent workgroups of an XCD work on ~32 CONSECUTIVE
+// tile ids at a time (xcd_remap): with the N index fastest (the default) those are 1 row-tile x 32 column-tiles - one A panel shared, 32
+// weight panels streamed, and every row-tile streams the whole weight matrix again (PMC: the level-2 GEGLU launch fetches 14 x its 52 MB
+// weight, profiles/r05_head_pmc_bf16x3m.md). Round 5 built the grouped order (GROUP_M row-tiles fastest inside a band of GROUP_M rows: the
+// 32 tiles become a GROUP_M x 32 / GROUP_M block) and measured it (profiles/r05_tile_order.md): L2-miss fetch of a U-Net forward 78.1 ->
+// 70.8 GB (-9 %), frames/s 5.925 -> 5.905 (-0.3 %, two interleaved pairs on one box): the misses are served from the Infinity Cache at
+// a rate the K loop does not wait for, while the grouped order shares each A panel among fewer neighbours. The column-fastest order
+// stays the default; debug_ablate = 16 + g selects GROUP_M = g. Same tiles, same arithmetic either way: bits unchanged.
 __device__ __forceinline__ void tile_of(long t, int tiles_n, int tiles_mn, int group_m, int& tm, int& tn) {
     const int tiles_m = tiles_mn / tiles_n;
     if (group_m <= 1 || tiles_n < 2 || tiles_m < 2) {
@@ -70,8 +72,8 @@ __device__ __forceinline__ void tile_of(long t, int tiles_n, int tiles_mn, int g
     tn = r / rows;
     tm = first_m + (r - tn * rows);
 }
-// debug_ablate 16 + g (A/B runs, tests): force GROUP_M = g (17 = the N-fastest order of rounds 1-4); otherwise 4
-__device__ __forceinline__ int tile_group_m(const geo4d_conv_gemm_t& p) { return (p.debug_ablate >= 16 && p.debug_ablate < 48) ? p.debug_ablate - 16 : 4; }
+// debug_ablate 16 + g (A/B runs, tests): GROUP_M = g; otherwise 1 = column-fastest
+__device__ __forceinline__ int tile_group_m(const geo4d_conv_gemm_t& p) { return (p.debug_ablate >= 16 && p.debug_ablate < 48) ? p.debug_ablate - 16 : 1; }
 
 // The two-pass f16 type stages ONLY the hi chunks of its activation panel (round 5, "A64"): it never multiplies the lo halves, and the
 // cost of staging is per 1 KB LDS-DMA request (profiles/r03_gemm_v2_explore_and_ablation.md), so the A panel's rows are 64 bytes - the

@@ -75,7 +75,7 @@ typedef struct geo4d_conv_gemm_t {
     int split_k;         /* 0 auto (powers of two), 1 never, n >= 2: n-way split (needs workspace; tile hints >= 21 take any n) */
     int debug_ablate;    /* 0 in production. 2 (tests only, tile hints >= 22): launch 3 persistent workgroups whatever the problem size,
                             so that small test shapes walk the persistent tile loop; 16 + g (A/B runs): tile order with GROUP_M = g row-tiles
-                            fastest (default 4; 17 = the column-fastest order of rounds 1-4) */
+                            fastest instead of the column-fastest default (-9 % L2-miss fetch, -0.3 % frames/s: profiles/r05_tile_order.md) */
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3): the operand is stored PRE-SPLIT, per 8 K-elements
                             [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32; dtype 4 (f16x2): both must
