@@ -746,7 +746,7 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 }
 
 // tile hints of the second generation (16x16x32 MFMA, register epilogue, persistent workgroups). Round 4 kept the five the measured
-// table selects (profiles/r04_gemm_census_vendor.md); 21 / 24 / 26 / 29 and the three-A-buffer twins 31..39 are gone:
+// table selects (profiles/r04_gemm_census_bf16x3.log); 21 / 24 / 26 / 29 and the three-A-buffer twins 31..39 are gone:
 //   22: 256x256, 8 waves (64x128 wave tiles)    23: 160x320, 8 waves (80x80)    25: 128x128, 4 waves (64x64)
 //   27: 64x128, 4 waves (32x64)                 28: 64x64, 4 waves (32x32)
 template <typename T>
