@@ -349,3 +349,38 @@ def test_bench_clip_mode_synthetic_scene_is_a_valid_alignment_input():
         f = estimate_focal_weiszfeld(p["raymap"][:2])
         assert torch.allclose(f, torch.full_like(f, 1.2 * W), rtol=1e-4)
     assert torch.allclose(traj[1, 3, :3, 3], torch.tensor([0.03, 0.0, 0.0]))      # the camera slides 0.01 per frame inside a window
+
+
+def test_two_pass_f16_host_side_contracts():
+    """Round 5 (bf16x3m): what the host decides without a GPU - the weight split represents w to ~22 bits for any scale and carries the
+    exact inverse of its power-of-two scale; the operand-format helpers tell the formats apart; the mode's class list is the documented
+    one and bf16x3 never takes a class."""
+    import torch
+    from geo4d_amd import ops, pack
+    from geo4d_amd.precision import TWO_PASS_CLASSES, resolve
+    g = torch.Generator().manual_seed(3)
+    for scale in (1e-5, 2e-3, 0.7, 40.0, 3e4):
+        w = torch.randn((24, 64), generator=g) * scale
+        wp = pack.split_f16(w)
+        assert wp.dtype == torch.float16 and wp.shape == (24, 128) and bool(torch.isfinite(wp.float()).all())
+        e = wp._x2_alpha
+        assert e > 0 and abs(torch.log2(torch.tensor(e)).item() - round(torch.log2(torch.tensor(e)).item())) < 1e-9      # an exact power of two
+        halves = wp.reshape(24, 8, 2, 8).double()
+        seen = (halves[:, :, 0] + halves[:, :, 1]).reshape(24, 64) * e
+        assert ((seen - w.double()).norm() / w.double().norm()).item() < 2e-6
+        assert halves[:, :, 0].abs().max().item() < 40000                                                                    # hi stays well inside the f16 range
+    z = pack.split_f16(torch.zeros((8, 16)))
+    assert z._x2_alpha == 1.0 and float(z.abs().max()) == 0.0
+    w = pack.split_f16(torch.randn((8, 32), generator=g))
+    x32, a16 = torch.randn((4, 32), generator=g), ops.new_split(4, 32, "cpu", "f16")
+    assert ops.is_x2_weight(w) and not ops.is_x2_weight(w.clone()) and ops.kdim(w, a16) == 32 and ops.act_k(a16) == 32      # (the scale travels as an attribute of THE packed tensor)
+    assert a16.dtype == torch.float16 and ops.new_split(4, 32, "cpu").dtype == torch.bfloat16
+    assert ops.split_fmt(False) == (0, None) and ops.split_fmt(True) == (1, "bf16") and ops.split_fmt("f16") == (2, "f16")
+    import pytest
+    with pytest.raises(ValueError):
+        ops.split_fmt("fp8")
+    assert {"conv3x3", "vae3x3", "tconv", "ln", "ff"} <= set(TWO_PASS_CLASSES) or "GEO4D_TWO_PASS" in os.environ
+    m, s = resolve("bf16x3m"), resolve("bf16x3")
+    assert m.x3 and m.two_pass_conv and m.storage == torch.float32 and m != s and resolve("mixed") == m
+    assert not any(s.two_pass(c) for c in ("conv3x3", "vae3x3", "tconv", "ln", "ff", "proj_in"))
+    assert all(m.two_pass(c) == (c in TWO_PASS_CLASSES) for c in ("conv3x3", "tconv", "ln", "ff", "proj_in", "proj_out"))
