@@ -57,6 +57,12 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5n)         # the other BASELINE configs on one GPU at HEAD (bf16x3m): configs[2] at the Sintel size, the 128-frame clip of configs[3], configs[4]'s 576x1024 batch; + one more default line (another box's headline)
+    timeout 600 python bench.py --clip-frames 64 --height 256 --width 576 > $O/bench_clip64_sintel.json 2> $O/bench_clip64_sintel.err; cut -c1-900 $O/bench_clip64_sintel.json | python -c "import sys,json; d=json.loads(sys.stdin.read()+'' if False else open('$O/bench_clip64_sintel.json').read()); print('configs[2] 64x256x576:', round(d['value'],3), d['unit'], d['phase_seconds'], d['alignment_vs_scene_truth'])"
+    timeout 600 python bench.py --clip-frames 128 > $O/bench_clip128.json 2> $O/bench_clip128.err; python -c "import json; d=json.load(open('$O/bench_clip128.json')); print('configs[3]-size 128x320x512:', round(d['value'],3), d['unit'], d['phase_seconds'])"
+    timeout 600 python bench.py --height 576 --width 1024 --batch 4 --dtype f16 --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-shipped-setting --no-clip-leg > $O/bench_configs4.json 2> $O/bench_configs4.err; python -c "import json; d=json.load(open('$O/bench_configs4.json')); print('configs[4] 4x16x576x1024 f16:', round(d['value'],3), d['unit'], round(d['ms_per_step']), 'ms per 4-clip step')"
+    ( time timeout 900 python bench.py --steps 5 --warmup 2 ) > $O/bench_default.json 2> $O/bench_default.err; python -c "import json; d=json.loads([l for l in open('$O/bench_default.json') if l.startswith('{')][-1]); print('default line:', round(d['value'],3), d['split_ms_per_step'], 'strict', round(d['strict_mode']['value'],3), 'fast', round(d['fast_mode']['value'],3), 'shipped', round(d['shipped_setting']['value'],2), 'clip s', round(d['clip_mode']['ms_per_step']/1e3,2), 'traffic GB', round((d['roofline']['traffic'] or 0)/1e9,1), d['roofline']['traffic_by_kernel_class_gb'])"
+    ;;
   r5m)         # r5l's A/B again with the switch actually reaching the library (bench only + the column-fastest PMC passes)
     run_bench() {   # name, extra env
       env $2 timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-shipped-setting > $O/bench_$1.json 2> $O/bench_$1.err
