@@ -726,8 +726,11 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     if constexpr (IsTwoPass<T>::value) {       // f16x2: pre-split x pre-split; plain f32 rows out, or (o_split = 2) the f16 pre-split format
         if (!p.a_split || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands; o_split 0 or 2 (f16 halves)"); return GEO4D_EINVAL; }
         if (p.o_split) {
-            if (o_split_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
-            geo4d_set_error("conv_gemm: o_split needs no split-K, N % 8 == 0 and 32-byte aligned output rows");
+            // (the f16-halves epilogue exists on the GEGLU-capable tiles only: its one user is the GEGLU -> ff-out chain)
+            if constexpr (((BN / WN / 16) % 4) == 0) {
+                if (o_split_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+            }
+            geo4d_set_error("conv_gemm: o_split = 2 needs a GEGLU-capable tile (wave tiles a multiple of 64 columns wide), no split-K, N % 8 == 0 and 32-byte aligned output rows");
             return GEO4D_EINVAL;
         }
         return launch_v2_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);

@@ -57,6 +57,12 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5z)         # last call of the round: HEAD as the driver will run it - the whole suite, smoke, a default bench line
+    ( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; grep -E "passed|failed|rc=|^FAILED|^ERROR" $O/pytest.log | tail -5
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
+    ( time timeout 900 python bench.py --steps 5 --warmup 2 ) > $O/bench.json 2> $O/bench.err; tail -4 $O/bench.err
+    python -c "import json; d=json.loads([l for l in open('$O/bench.json') if l.startswith('{')][-1]); print('default line:', d['dtype'], round(d['value'],3), d['split_ms_per_step'], 'strict', round(d['strict_mode']['value'],3), 'fast', round(d['fast_mode']['value'],3), 'shipped', round(d['shipped_setting']['value'],2), 'clip s', round(d['clip_mode']['ms_per_step']/1e3,2), 'frac', round(d['roofline']['frac'],4), 'issued', round(d['roofline']['frac_issued'],3), 'attn issued', round(d['roofline']['attention']['frac_issued'],3))"
+    ;;
   r5n)         # the other BASELINE configs on one GPU at HEAD (bf16x3m): configs[2] at the Sintel size, the 128-frame clip of configs[3], configs[4]'s 576x1024 batch; + one more default line (another box's headline)
     timeout 600 python bench.py --clip-frames 64 --height 256 --width 576 > $O/bench_clip64_sintel.json 2> $O/bench_clip64_sintel.err; cut -c1-900 $O/bench_clip64_sintel.json | python -c "import sys,json; d=json.loads(sys.stdin.read()+'' if False else open('$O/bench_clip64_sintel.json').read()); print('configs[2] 64x256x576:', round(d['value'],3), d['unit'], d['phase_seconds'], d['alignment_vs_scene_truth'])"
     timeout 600 python bench.py --clip-frames 128 > $O/bench_clip128.json 2> $O/bench_clip128.err; python -c "import json; d=json.load(open('$O/bench_clip128.json')); print('configs[3]-size 128x320x512:', round(d['value'],3), d['unit'], d['phase_seconds'])"
