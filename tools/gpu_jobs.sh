@@ -57,6 +57,21 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5y)         # a second same-box A/B against the round-4 end state (gpurun_ab_r4/ built on the box), on whatever box this call gets
+    cd $R/gpurun_ab_r4 && ( time make -j64 > $O/build_r4.log 2>&1 ) 2>&1 | grep real
+    for i in 1 2; do
+      cd $R/gpurun_ab_r4 && timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/ab_r4_$i.json 2> $O/ab_r4_$i.err
+      cd $R && timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/ab_r5_$i.json 2> $O/ab_r5_$i.err
+    done
+    cd $R && python - <<PY
+import json
+for n in ("ab_r4_1", "ab_r5_1", "ab_r4_2", "ab_r5_2"):
+    try:
+        d = json.load(open("$O/%s.json" % n)); print(n, d["dtype"], round(d["value"], 3), "frames/s", {k: round(v) for k, v in d["split_ms_per_step"].items()}, "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+    except Exception as e:
+        print(n, "failed", e)
+PY
+    ;;
   r5z)         # last call of the round: HEAD as the driver will run it - the whole suite, smoke, a default bench line
     ( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; grep -E "passed|failed|rc=|^FAILED|^ERROR" $O/pytest.log | tail -5
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
