@@ -70,7 +70,7 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
             geo4d_set_error("conv_gemm: f16x2 (dtype 4) needs a_split and w_split, a row-major f32 output (o_split 0, or 2 = f16 halves), and tile hint 0 or >= 22");
             return GEO4D_EINVAL;
         }
-        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? (p.act == 2 ? 71 : 72) : 25;      // (GEGLU: wave tiles a multiple of 64 columns wide)      // (GEGLU: wave tiles a multiple of 64 columns wide)
+        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? (p.act == 2 ? 71 : 72) : 25;      // (GEGLU: wave tiles a multiple of 64 columns wide)
         if (p.split_k == 0) p.split_k = 1;
     }
     if (p.o_split) {
