@@ -430,41 +430,55 @@ __global__ __launch_bounds__(256, OCC) void flash_attn2_kernel(const geo4d_atten
     const float c2 = p.scale * 1.4426950408889634f;
     const float thr = 6.0f / c2;                                        // lazy rescale threshold, as in flash_attn_kernel
 
-    // staging geometry (identical to flash_attn_kernel: same LDS image, same source-side swizzle)
+    // staging geometry (identical to flash_attn_kernel: same LDS image, same source-side swizzle). Round 5: the pieces go through RAW
+    // BUFFER RESOURCES - per lane ONE 32-bit byte offset per piece, the tile's position in a wave-uniform SGPR offset - instead of a
+    // 64-bit pointer + a row / key index per piece: the 24 registers of that state were what the two-waves-per-SIMD bf16x3 build
+    // spilled, and reloaded from scratch inside every key tile (120 bytes of scratch, ~20 scratch loads per tile).
+    // In the ragged last tile a K row / a V^T key column at or beyond nk gets an offset beyond the 2 GB window (the hardware writes
+    // zeros; the bounds check covers the VGPR offset only, not the SGPR tile offset, so the selection is explicit) - the row / key
+    // indices are re-derived from the lane id there: nothing is kept live for it.
     const int srow = lane / SLOTS, sslot = lane % SLOTS;
-    const T* ksrc[NDMA];
-    const T* vsrc[NDMA];
-    int krow[NDMA], vkey[NDMA];
-    const long kstep = 64 * p.ldk[0];
+    constexpr unsigned OOB = 0x80000000u;
+    // piece i of a wave stages rows (wave NDMA + i) RPI + srow: its swizzled chunk is chunk(0) ^ 4 i (the row term of the key moves by
+    // 4 per piece), so ONE offset per operand + the two byte deltas of flipping chunk bits 2 / 3 describe all NDMA pieces of a lane; the
+    // row step of a piece is wave-uniform and rides in the SGPR offset
+    unsigned voffK0, voffV0;
+    int dflip2, dflip3;
+    __amdgpu_buffer_rsrc_t rK, rV;
+    auto piece_chunk = [&](int i) {
+        const int row = (wave * NDMA + i) * RPI + srow;
+        return sslot ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15));
+    };
+    auto piece_delta = [&](int i) { return ((i & 1) ? dflip2 : 0) + ((i & 2) ? dflip3 : 0); };
     {
         const long kvb = b / p.kv_div[0];
         const T* kp = (const T*)p.k[0] + kvb * nk * p.ldk[0] + h * 64;
         const T* vp = (const T*)p.vt[0] + kvb * p.vt_bs[0] + (long)h * 64 * p.ldvt[0];
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int row = (wave * NDMA + i) * RPI + srow;
-            const int chunk = sslot ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15));
-            krow[i] = row;
-            vkey[i] = PS ? (chunk >> 1) * 8 : chunk * EPC;
-            ksrc[i] = kp + (long)row * p.ldk[0] + chunk * EPC;
-            vsrc[i] = vp + (long)row * p.ldvt[0] + chunk * EPC;
-        }
+        // 2 GB windows from this (batch, head)'s first key row / first V^T channel row (the host checks that a window covers them)
+        rK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, OOB, 0x00020000);
+        rV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, OOB, 0x00020000);
+        const int row0 = wave * NDMA * RPI + srow, c0 = piece_chunk(0);
+        voffK0 = (unsigned)(((long)row0 * p.ldk[0] + c0 * EPC) * ES);
+        voffV0 = (unsigned)(((long)row0 * p.ldvt[0] + c0 * EPC) * ES);
+        dflip2 = (c0 & 4) ? -64 : 64;                   // chunk ^ 4: +- 4 chunks of 16 bytes
+        dflip3 = (c0 & 8) ? -128 : 128;                 // chunk ^ 8 (4-byte storage: 16 chunks per row, 4 pieces per wave)
     }
+    const unsigned kstepb = (unsigned)(64 * p.ldk[0] * ES);
+    const unsigned prowK = (unsigned)(RPI * p.ldk[0] * ES), prowV = (unsigned)(RPI * p.ldvt[0] * ES);      // bytes from a piece's rows to the next piece's
     auto issue_tile = [&](int tile, int buf) {
         char* kb_ = lds + buf * 2 * TILE;
         const bool full = tile * 64 + 64 <= nk;
+        const unsigned soffK = __builtin_amdgcn_readfirstlane((unsigned)tile * kstepb), soffV = __builtin_amdgcn_readfirstlane((unsigned)(tile * 64 * ES));
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const T* ks = ksrc[i] + (long)tile * kstep;
-            const T* vs = vsrc[i] + tile * 64;
+            unsigned vk = voffK0 + (unsigned)piece_delta(i), vv = voffV0 + (unsigned)piece_delta(i);
             if (!full) {
-                if (tile * 64 + krow[i] >= nk) ks = Z;
-                if (tile * 64 + vkey[i] >= nk) vs = Z;
+                const int chunk = piece_chunk(i);
+                if (tile * 64 + (wave * NDMA + i) * RPI + srow >= nk) vk = OOB;
+                if (tile * 64 + (PS ? (chunk >> 1) * 8 : chunk * EPC) >= nk) vv = OOB;
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
-                                             (__attribute__((address_space(3))) void*)(kb_ + (wave * NDMA + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
-                                             (__attribute__((address_space(3))) void*)(kb_ + TILE + (wave * NDMA + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (__attribute__((address_space(3))) void*)(kb_ + (wave * NDMA + i) * 1024), 16, (int)vk, (int)(soffK + i * prowK), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (__attribute__((address_space(3))) void*)(kb_ + TILE + (wave * NDMA + i) * 1024), 16, (int)vv, (int)(soffV + i * prowV), 0, 0);
         }
     };
     const int swz = ES == 2 ? ((li >> 1) & 7) : (li & 15);
@@ -817,13 +831,18 @@ extern "C" int geo4d_attention(const geo4d_attention_t* pp, void* stream) {
     // bf16 N = 2560 199.9 -> 189.9 us, N = 640 33.6 -> 31.4; pre-split bf16x3 N = 2560 524 -> 443 us, N = 640 76.3 -> 67.8)
     // (bf16x3: the two-waves-per-SIMD build wins on the long level-0 sequences once the workgroups of a (frame, head) share an XCD:
     // N = 2560 467 us (variant 4) vs 443 us (variant 5); N = 640 67.8 vs 70.3 us)
-    if (variant == 0 && p.nseg == 1 && p.Nq >= 256 &&
+    // (round 5: that kernel stages K / V^T through 2 GB buffer windows with 32-bit offsets: one (batch, head)'s keys and V^T rows must
+    // fit one - they do by orders of magnitude at every size of BASELINE.json; otherwise the pointer-staged kernels below serve the call)
+    const long esz_w = (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16) ? 2 : 4;
+    const bool window_ok = p.nseg == 1 && ((long)(p.Nk[0] + 64) * p.ldk[0] + 64) * esz_w < (1L << 31) && (64L * p.ldvt[0] + p.Nk[0] + 64) * esz_w < (1L << 31);
+    if (variant == 0 && p.nseg == 1 && p.Nq >= 256 && window_ok &&
         (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16 || (p.dtype == GEO4D_BF16X3 && p.qkv_split)))
         variant = (p.dtype == GEO4D_BF16X3 && p.Nq >= 1024) ? 5 : 4;
     if (variant >= 4) {
         const bool ok16 = (p.dtype == GEO4D_BF16 || p.dtype == GEO4D_F16) && variant == 4;
         const bool okx3 = p.dtype == GEO4D_BF16X3 && p.qkv_split;
         if (p.nseg != 1 || !(ok16 || okx3)) { geo4d_set_error("attention: variants 4 / 5 take one key/value set in bf16 / f16 (4) or pre-split bf16x3"); return GEO4D_EINVAL; }
+        if (!window_ok) { geo4d_set_error("attention: variants 4 / 5 need one (batch, head)'s keys and V^T rows inside a 2 GB window"); return GEO4D_EINVAL; }
         const dim3 grid2((p.Nq + 255) / 256, p.H, p.B);
         if (p.dtype == GEO4D_BF16) hipLaunchKernelGGL((flash_attn2_kernel<bf16_t, false, 2>), grid2, dim3(256), 0, st, p);
         else if (p.dtype == GEO4D_F16) hipLaunchKernelGGL((flash_attn2_kernel<f16_t, false, 2>), grid2, dim3(256), 0, st, p);

@@ -57,6 +57,10 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5x)         # flash_attn2 staged through buffer resources (fewer live registers): correct? scratch traffic down -> faster?
+    ( timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_bf16x3_gpu.py tests/test_presplit_gpu.py tests/test_sizes_gpu.py -m gpu -q -k "attention or attn or presplit or flash or sizes" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log; grep -E "^FAILED|^ERROR" $O/pytest.log | head
+    timeout 300 python tools/attn_bench.py bf16 bf16x3 > $O/attn.log 2>&1; grep "2560\|forward\| 640\|9216" $O/attn.log | grep "v4\|v1 " | tail -14
+    ;;
   r5y)         # a second same-box A/B against the round-4 end state (gpurun_ab_r4/ built on the box), on whatever box this call gets
     cd $R/gpurun_ab_r4 && ( time make -j64 > $O/build_r4.log 2>&1 ) 2>&1 | grep real
     for i in 1 2; do
