@@ -92,8 +92,9 @@ def test_phased_k_loop_keeps_its_pipeline(name, targs, nwait):
 def test_built_library_scratch_is_confined_to_the_listed_kernels():
     """Every kernel of the built libgeo4d_hip.so, read from the code objects' metadata (tools/so_kernel_table.py): spilled registers
     (scratch) only in the kernels LISTED here, each with its bound. Two of the listed ones ARE on the product path and are a known debt
-    (VERDICT r4 weak #3): `flash_attn2_kernel<bf16x3_t, true, 2>` (the default spatial self-attention of the bf16x3 modes: 120 bytes,
-    9 registers over its 256-register budget at two waves per SIMD - measured faster than the spill-free one-wave build all the same) and
+    (VERDICT r4 weak #3): `flash_attn2_kernel<bf16x3_t, true, 2>` (the default spatial self-attention of the bf16x3 modes: 76 bytes
+    since round 5 staged K / V^T through buffer resources - 120 before -, still ~20 registers over its 256-register budget at two waves
+    per SIMD; measured faster than the spill-free one-wave build all the same) and
     the 256x256 second-generation GEMM tile (24-32 bytes spilled before the K loop, reloaded in the epilogue). The other attention
     instantiations in the list are A/B builds ops.attention only launches on request (variant 1..3)."""
     import sys
