@@ -57,6 +57,25 @@ PY
     [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 16 > $O/phases_bf16x3m.md 2>&1
     head -5 $O/phases_bf16x3m.md | cut -c1-600
     ;;
+  r5final)     # the round's last call: HEAD as the driver will run it (suite, smoke, default line) + the trace / PMC evidence of that very tree
+    ( time timeout 1500 python -m pytest tests -m gpu -q -x -s ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; grep -E "passed|failed|rc=|^FAILED|^ERROR" $O/pytest.log | tail -5
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
+    ( time timeout 900 python bench.py --steps 5 --warmup 2 ) > $O/bench.json 2> $O/bench.err; tail -4 $O/bench.err
+    python -c "import json; d=json.loads([l for l in open('$O/bench.json') if l.startswith('{')][-1]); print('default line:', d['dtype'], round(d['value'],3), d['split_ms_per_step'], 'strict', round(d['strict_mode']['value'],3), 'fast', round(d['fast_mode']['value'],3), 'shipped', round(d['shipped_setting']['value'],2), 'clip s', round(d['clip_mode']['ms_per_step']/1e3,2), 'frac', round(d['roofline']['frac'],4), 'issued', round(d['roofline']['frac_issued'],3), 'attn issued', round(d['roofline']['attention']['frac_issued'],3))"
+    cd /tmp
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-shipped-setting --no-clip-leg > $O/kt.log 2>&1
+    find /tmp/prof/kt -name "*kernel_stats.csv" -exec cp {} $O/kt_kernel_stats.csv \;
+    KT=$(find /tmp/prof/kt -name "*kernel_trace.csv" | head -1)
+    [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 30 > $O/phases.md 2>&1
+    head -16 $O/phases.md | cut -c1-300
+    i=0
+    for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof/pmc$i -o p -- python $R/tools/profile_unet.py 1 bf16x3m > $O/pmc$i.log 2>&1
+    done
+    python $R/tools/pmc_summary.py $O/pmc.md $O/pmc.json $(find /tmp/prof/pmc1 /tmp/prof/pmc2 /tmp/prof/pmc3 -name "*counter_collection.csv") > $O/pmc_summary.log 2>&1
+    grep "whole forward" $O/pmc.md; tail -9 $O/pmc.md
+    ;;
   r5x)         # flash_attn2 staged through buffer resources (fewer live registers): correct? scratch traffic down -> faster?
     ( timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_bf16x3_gpu.py tests/test_presplit_gpu.py tests/test_sizes_gpu.py -m gpu -q -k "attention or attn or presplit or flash or sizes" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log; grep -E "^FAILED|^ERROR" $O/pytest.log | head
     timeout 300 python tools/attn_bench.py bf16 bf16x3 > $O/attn.log 2>&1; grep "2560\|forward\| 640\|9216" $O/attn.log | grep "v4\|v1 " | tail -14
