@@ -2,6 +2,11 @@
 # One entry point for the GPU-box jobs of a round: `gpurun --timeout N -- 'bash tools/gpu_jobs.sh <job> [args]'`.
 # Every job writes under gpurun_out/<tag>/ (merged back by gpurun); summaries worth judging are copied into profiles/ by hand.
 # (Rounds 2-3 kept one script per call under tools/r0*_runs/: those are in the history; this file replaces the pattern.)
+# Round 5's calls, in order: r5a (two-pass f16 GEMM: first measurement) r5b (census of every row in two passes) r5c (classes widened)
+# r5d (stream-rounding classes: measured, later removed) r5e / r5f (suite dry runs) r5g (phases of a step) r5h (one-launch GroupNorm: slower)
+# r5i (A64) r5j (320x160 tile: no gain) r5k (same-box A/B of A64) r5l / r5m (grouped tile order) r5n (the other BASELINE configs)
+# r5x (attention staging) r5y (same-box A/B vs round 4) r5z / r5final (HEAD as the driver runs it + its trace / PMC); tools/round_end_gpu.sh
+# is the all-in-one evidence job. A job that names build_b/ or gpurun_ab_r4/ needs that directory prepared in the container first.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 JOB=${1:?job name}; shift
 TAG=${TAG:-r5_$JOB}
