@@ -315,6 +315,10 @@ SCHEMES = [
     Scheme("bf16", "bf16", "bf16", name="bf16 everywhere (round-1 bench mode)"),
     Scheme("bf16", "bf16", "f32", name="bf16 operands, fp32 residual streams"),
     Scheme("bf16x2", "bf16x2", "f32", name="bf16x3 mode: f32 storage, operands split hi+lo, 3 bf16 MFMAs per product"),
+    # round 5: two-pass f16 products (A one f16, W f16 hi + lo) on classes of GEMMs, everything else as bf16x3 (profiles/r05_mixed_pass_sim.md)
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", name="two-pass f16 on the U-Net's 3x3 convs"),
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff"), name="bf16x3m mode: two-pass f16 on conv3x3 + vae3x3 + tconv + ln + ff"),
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff", "proj_in", "proj_out", "raw"), name="... + the stream-rounding classes (proj_in / proj_out / raw): rejected"),
 ]
 
 
