@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- MUST precede loading the .so: PyTorch ships its o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GEO4D_HIP_LIB: load another build of the SAME library (A/B builds of a kernel: tools/gpu_r2k.sh); the ABI handshake below still applies
 LIB_PATH = os.environ.get("GEO4D_HIP_LIB") or os.path.join(_HERE, "csrc", "libgeo4d_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 F32, BF16, F16, BF16X3, F16X2 = 0, 1, 2, 3, 4
 
@@ -37,7 +37,7 @@ class ConvGemm(C.Structure):
         ("rowbias_div", C.c_int), ("bias_per_row", C.c_int), ("act", C.c_int),
         ("dtype", C.c_int), ("out_dtype", C.c_int), ("out_nchw", C.c_int), ("tile_hint", C.c_int),
         ("split_k", C.c_int), ("debug_ablate", C.c_int), ("alpha", C.c_float),
-        ("a_split", C.c_int), ("w_split", C.c_int), ("o_split", C.c_int), ("gn_colsum", C.c_void_p),
+        ("a_split", C.c_int), ("w_split", C.c_int), ("o_split", C.c_int), ("gn_colsum", C.c_void_p), ("sat_count", C.c_void_p),
     ]
 
 
@@ -48,6 +48,7 @@ class GroupNorm(C.Structure):
         ("ldx", C.c_long), ("ldy", C.c_long),
         ("F", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("frames_per_stat", C.c_int),
         ("act", C.c_int), ("dtype", C.c_int), ("eps", C.c_float), ("colsum", C.c_void_p), ("split_out", C.c_int), ("colsum_rows", C.c_int),
+        ("sat_count", C.c_void_p),
     ]
 
 
@@ -101,7 +102,7 @@ SIGNATURES = {
     "geo4d_layernorm": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p]),
     "geo4d_layernorm_split": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_void_p,
-                                        C.c_void_p, C.c_int, C.c_void_p]),
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "geo4d_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_int,
                                      C.c_void_p]),
     "geo4d_softmax_rows_causal": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_int,

@@ -21,8 +21,9 @@
 #define GEO4D_BF16 1
 #define GEO4D_F16 2
 #define GEO4D_BF16X3 3   // f32 STORAGE, bf16 MFMA on a 3-term hi/lo split (x_hi.w_hi + x_hi.w_lo + x_lo.w_hi): ~16-bit mantissas
-#define GEO4D_F16X2 4    // conv_gemm only, PRE-SPLIT operands only: [8 x f16 hi | 8 x f16 lo] per 8 K-elements; product = a_hi.w_hi + a_hi.w_lo
-                         // (two f16 MFMAs): the activation carries 11 mantissa bits, the weight ~22 (round 5, the long-K 3x3 convolutions)
+#define GEO4D_F16X2 4    // conv_gemm only: the weight PRE-SPLIT as [8 x f16 hi | 8 x f16 lo] per 8 K-elements, the activation PLAIN f16 rows (round 6;
+                         // round 5 stored an unread lo half beside it); product = a.w_hi + a.w_lo (two f16 MFMAs): the activation carries 11
+                         // mantissa bits, the weight ~22
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -41,9 +42,9 @@ struct f16_t { unsigned short v; };
 // split once at pack time and stored per 8 K-elements as [8 x bf16 hi | 8 x bf16 lo] (two 16-byte chunks = the same 32 bytes
 // 8 f32 would take), so a fragment read is the same two ds_read_b128 for both layouts.
 struct bf16x3_t { float v; };
-// "f16x2" (round 5): the same 4 bytes per K element and the same [8 hi | 8 lo] grouping, with f16 halves, and only the activation's
-// HI half is multiplied: a.w ~ a_hi.w_hi + a_hi.w_lo - two f16 MFMAs per product instead of three bf16 ones. The activation is an f16
-// (11 bits), the weight hi + lo ~22 bits (pre-scaled by a power of two at pack time so that lo stays out of the f16 subnormals; the
+// "f16x2" (round 5): the WEIGHT keeps 4 bytes per K element in the same [8 hi | 8 lo] grouping with f16 halves; the ACTIVATION is one f16
+// per element (round 6: stored as plain f16 rows, 2 bytes per element): a.w ~ a.w_hi + a.w_lo - two f16 MFMAs per product instead of
+// three bf16 ones. The activation is an f16 (11 bits), the weight hi + lo ~22 bits (pre-scaled by a power of two at pack time so that lo stays out of the f16 subnormals; the
 // launch's alpha undoes the scale). Why that is enough for the long-K 3x3 convolutions and only for them: tests/precision_sim.py,
 // tests/test_precision_floor.py (point-map drift 1.3e-4 .. 2.9e-4 where a full f16 pass costs 2e-3).
 struct f16x2p_t { float v; };
@@ -201,18 +202,28 @@ __device__ __forceinline__ void store_split4(void* row_base, int cc, const float
     *(u32x2*)g = u32x2{h0, h1};
     *(u32x2*)(g + 16) = u32x2{l0, l1};
 }
-// the f16x2 producers' form of store_split4: f16 hi | f16 lo (the consumer GEMM reads hi only; lo keeps the format self-describing).
-// Values are clamped to the f16 range first: an overflow would reach the MFMA as inf.
-__device__ __forceinline__ void store_split4_f16(void* row_base, int cc, const float* e) {
-    float c[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = fminf(fmaxf(e[j], -65504.0f), 65504.0f);
-    const unsigned int h0 = f32x2_to_f16x2(c[0], c[1]), h1 = f32x2_to_f16x2(c[2], c[3]);
-    const unsigned int l0 = f32x2_to_f16x2(c[0] - f16_bits_to_f32((unsigned short)(h0 & 0xffffu)), c[1] - f16_bits_to_f32((unsigned short)(h0 >> 16)));
-    const unsigned int l1 = f32x2_to_f16x2(c[2] - f16_bits_to_f32((unsigned short)(h1 & 0xffffu)), c[3] - f16_bits_to_f32((unsigned short)(h1 >> 16)));
-    char* g = (char*)row_base + (cc >> 1) * 32 + (cc & 1) * 8;
-    *(u32x2*)g = u32x2{h0, h1};
-    *(u32x2*)(g + 16) = u32x2{l0, l1};
+// the f16x2 producers' form (round 6: PLAIN f16 rows - the two-pass consumer multiplies only the activation's f16 value, so there is
+// no lo half to keep: 2 bytes per element written, 64 contiguous bytes per K slab read). Values are clamped to the finite f16 range first
+// (an overflow would reach the MFMA as inf); a NaN stays a NaN, so a diverged activation is still visible downstream.
+__device__ __forceinline__ float clamp_f16_range(float e) {
+    const float c = fminf(fmaxf(e, -65504.0f), 65504.0f);
+    return e != e ? e : c;
+}
+__device__ __forceinline__ u32x2 pack4_f16_sat(const float* e) {
+    return u32x2{f32x2_to_f16x2(clamp_f16_range(e[0]), clamp_f16_range(e[1])), f32x2_to_f16x2(clamp_f16_range(e[2]), clamp_f16_range(e[3]))};
+}
+// debug counter of the clamping stores (geo4d_conv_gemm_t.sat_count & co; NULL in production): += the lanes of this wave that hold a value
+// beyond the finite f16 range (|e| > 65504, inf included; NaN is not a saturation). One atomic per wave that saw any. Wave-uniform call sites only.
+__device__ __forceinline__ void count_f16_saturation(unsigned long long* counter, const float* e) {
+    if (counter) {
+        const bool any = fabsf(e[0]) > 65504.0f || fabsf(e[1]) > 65504.0f || fabsf(e[2]) > 65504.0f || fabsf(e[3]) > 65504.0f;
+        const unsigned long long b = __ballot(any);
+        if (b && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)b) - 1)) atomicAdd(counter, (unsigned long long)__popcll(b));
+    }
+}
+// `row_base` = first byte of the f16 row, `cc` = index of the 4-element group inside the row
+__device__ __forceinline__ void store4_f16(void* row_base, int cc, const float* e) {
+    *(u32x2*)((char*)row_base + cc * 8) = pack4_f16_sat(e);
 }
 __device__ __forceinline__ void store_split8(void* row_base, int group8, const float* e) {
     u32x4 hi, lo;

@@ -65,18 +65,20 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     if (p.dtype < 0 || p.dtype > 4 || p.out_dtype < 0 || p.out_dtype > 2) { geo4d_set_error("conv_gemm: bad dtype"); return GEO4D_EINVAL; }
     if (p.dtype != GEO4D_BF16X3 && p.dtype != GEO4D_F16X2 && (p.a_split || p.w_split)) { geo4d_set_error("conv_gemm: a_split / w_split are bf16x3 / f16x2 (dtype 3 / 4) options"); return GEO4D_EINVAL; }
     if (p.dtype == GEO4D_F16X2) {
-        // two-pass f16: pre-split x pre-split operands, plain f32 rows out, second / third generation tiles (0 = a default per shape)
-        if (!p.a_split || !p.w_split || (p.o_split != 0 && p.o_split != 2) || p.out_nchw || p.out_dtype != GEO4D_F32 || (p.tile_hint != 0 && p.tile_hint < 22)) {
-            geo4d_set_error("conv_gemm: f16x2 (dtype 4) needs a_split and w_split, a row-major f32 output (o_split 0, or 2 = f16 halves), and tile hint 0 or >= 22");
+        // two-pass f16: plain f16 activation rows x a pre-split f16 weight, f32 rows (or, o_split = 2, plain f16 rows) out, second / third
+        // generation tiles (0 = a default per shape)
+        if (p.a_split != 2 || !p.w_split || (p.o_split != 0 && p.o_split != 2) || p.out_nchw || p.out_dtype != GEO4D_F32 || (p.tile_hint != 0 && p.tile_hint < 22)) {
+            geo4d_set_error("conv_gemm: f16x2 (dtype 4) needs a_split = 2 (plain f16 activation rows) and w_split, a row-major output (f32 rows, or o_split = 2: plain f16 rows), and tile hint 0 or >= 22");
             return GEO4D_EINVAL;
         }
-        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? (p.act == 2 ? 71 : 72) : 25;      // (GEGLU: wave tiles a multiple of 64 columns wide)
+        // (GEGLU and the f16-row epilogue live on the tiles whose wave tiles are a multiple of 64 columns wide)
+        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? ((p.act == 2 || p.o_split) ? 71 : 72) : 25;
         if (p.split_k == 0) p.split_k = 1;
     }
     if (p.o_split) {
         const int nst = p.act == 2 ? p.N / 2 : p.N;
         if ((p.dtype != GEO4D_BF16X3 && p.dtype != GEO4D_F16X2) || (p.dtype == GEO4D_BF16X3 && p.o_split != 1) || p.out_dtype != GEO4D_F32 || !p.a_split || !p.w_split || p.split_k > 1 || p.out_nchw || p.gn_colsum ||
-            (nst % 8) || (p.ldo % 8) || (p.o_bs % 8) || ((uintptr_t)p.O % 32)) {
+            (nst % 8) || (p.ldo % 8) || (p.o_bs % 8) || ((uintptr_t)p.O % (p.o_split == 2 ? 16 : 32))) {
             geo4d_set_error("conv_gemm: o_split needs a pre-split x pre-split bf16x3 launch, f32 row-major output, stored columns % 8 == 0, 32-byte aligned rows, no split-K");
             return GEO4D_EINVAL;
         }
@@ -84,7 +86,8 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) { geo4d_set_error("conv_gemm: empty problem"); return GEO4D_EINVAL; }
     if (p.KT <= 0 || p.KH <= 0 || p.KW <= 0 || p.KT * p.KH * p.KW > MAXTAP) { geo4d_set_error("conv_gemm: at most 9 taps"); return GEO4D_EINVAL; }
     if (p.Cin % bk || p.K != p.Cin * p.KT * p.KH * p.KW) { geo4d_set_error("conv_gemm: Cin must be a multiple of the 128-byte K slab and K = taps*Cin"); return GEO4D_EINVAL; }
-    if ((p.lda * esz) % 16 || (p.ldw * esz) % 16 || ((uintptr_t)p.A % 16) || ((uintptr_t)p.W % 16) || (p.a_bs * esz) % 16 || (p.w_bs * esz) % 16) {
+    const int esz_a = p.dtype == GEO4D_F16X2 ? 2 : esz;      // (dtype 4: the activation is plain f16 rows)
+    if ((p.lda * esz_a) % 16 || (p.ldw * esz) % 16 || ((uintptr_t)p.A % 16) || ((uintptr_t)p.W % 16) || (p.a_bs * esz_a) % 16 || (p.w_bs * esz) % 16) {
         geo4d_set_error("conv_gemm: operands must be 16-byte aligned");
         return GEO4D_EINVAL;
     }

@@ -75,9 +75,11 @@ __device__ __forceinline__ void tile_of(long t, int tiles_n, int tiles_mn, int g
 // debug_ablate 16 + g (A/B runs, tests): GROUP_M = g; otherwise 1 = column-fastest
 __device__ __forceinline__ int tile_group_m(const geo4d_conv_gemm_t& p) { return (p.debug_ablate >= 16 && p.debug_ablate < 48) ? p.debug_ablate - 16 : 1; }
 
-// The two-pass f16 type stages ONLY the hi chunks of its activation panel (round 5, "A64"): it never multiplies the lo halves, and the
-// cost of staging is per 1 KB LDS-DMA request (profiles/r03_gemm_v2_explore_and_ablation.md), so the A panel's rows are 64 bytes - the
-// four hi chunks of a 32-k slab - and a request covers 16 rows instead of 8: half the A-side requests, same arithmetic, same bits.
+// The two-pass f16 type's activation panel has 64-byte rows (round 5, "A64"): it multiplies ONE f16 per activation element, and the
+// cost of staging is per 1 KB LDS-DMA request (profiles/r03_gemm_v2_explore_and_ablation.md), so a request covers 16 rows of the 32-k slab
+// instead of 8: half the A-side requests. Round 5 fetched the four hi chunks out of [8 hi | 8 lo] groups (16 of every 32 bytes of a row
+// whose lo halves nobody read); round 6: the producers write PLAIN f16 rows and a panel row is 64 CONTIGUOUS bytes of the source row -
+// the same LDS image, the same arithmetic, the same bits, half the activation bytes written and fetched.
 // LDS slot of K-group g in panel row r = g ^ swz_key_a64(r); ds_read_b128 service groups (see swz_key): with 4 slots per row the 16
 // lanes of a group hit 16 distinct 16-byte bank groups when rows {0-3, 4-7, 8-11, 12-15} of a 16-row block are keyed {0, 3, 2, 1}.
 __device__ __forceinline__ int swz_key_a64(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -114,7 +116,7 @@ __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 la
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));     // row_mirror
     return v;
 }
-template <int MB, int NB, bool OSPLIT, bool VECONLY = false, bool ROWS4 = false, bool OH = false>   // OH: the pre-split output's halves are f16 (the two-pass f16 type: o_split = 2) instead of bf16; VECONLY: the host checked the vector-store conditions (no scalar fallback code); ROWS4: 4-byte element kernels (bf16x3) - the 16-bit-row fast paths are not instantiated
+template <int MB, int NB, bool OSPLIT, bool VECONLY = false, bool ROWS4 = false, bool OH = false>   // OH: the two-pass f16 type - its OSPLIT output (o_split = 2) is PLAIN f16 rows instead of bf16 hi | lo halves; VECONLY: the host checked the vector-store conditions (no scalar fallback code); ROWS4: 4-byte element kernels (bf16x3) - the 16-bit-row fast paths are not instantiated
 __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f32x4 (&acc)[MB][NB], const int m_w0, const int n_w0,
                                              const long e_bz, const int e_kz, const bool partial, const int lr, const int lq) {
     const int odt = partial ? GEO4D_F32 : p.out_dtype;
@@ -134,18 +136,9 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
     auto chunk_of = [&](const float (&e)[4]) __attribute__((always_inline)) -> u32x4 {
         if constexpr (OSPLIT) {
             unsigned int h0, h1, l0, l1;
-            if constexpr (OH) {      // f16 hi | lo of the value clamped to the f16 range (store_split4_f16's arithmetic)
-                float c[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] = fminf(fmaxf(e[j], -65504.0f), 65504.0f);
-                h0 = f32x2_to_f16x2(c[0], c[1]); h1 = f32x2_to_f16x2(c[2], c[3]);
-                l0 = f32x2_to_f16x2(c[0] - f16_bits_to_f32((unsigned short)(h0 & 0xffffu)), c[1] - f16_bits_to_f32((unsigned short)(h0 >> 16)));
-                l1 = f32x2_to_f16x2(c[2] - f16_bits_to_f32((unsigned short)(h1 & 0xffffu)), c[3] - f16_bits_to_f32((unsigned short)(h1 >> 16)));
-            } else {
-                h0 = f32x2_to_bf16x2(e[0], e[1]); h1 = f32x2_to_bf16x2(e[2], e[3]);
-                l0 = f32x2_to_bf16x2(e[0] - __uint_as_float(h0 << 16), e[1] - __uint_as_float(h0 & 0xffff0000u));
-                l1 = f32x2_to_bf16x2(e[2] - __uint_as_float(h1 << 16), e[3] - __uint_as_float(h1 & 0xffff0000u));
-            }
+            h0 = f32x2_to_bf16x2(e[0], e[1]); h1 = f32x2_to_bf16x2(e[2], e[3]);
+            l0 = f32x2_to_bf16x2(e[0] - __uint_as_float(h0 << 16), e[1] - __uint_as_float(h0 & 0xffff0000u));
+            l1 = f32x2_to_bf16x2(e[2] - __uint_as_float(h1 << 16), e[3] - __uint_as_float(h1 & 0xffff0000u));
             // rows of 16 lanes = lq: odd rows of (h) <-> even rows of (l): even lq ends with [h own | h of lq + 1] = the group's hi chunk,
             // odd lq with [l of lq - 1 | l own] = its lo chunk (every lane of the wave takes part: no divergence before this point)
             const u32x2 s0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false);
@@ -155,6 +148,61 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
             return u32x4{__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
         }
     };
+    if constexpr (OSPLIT && OH) {
+        // o_split = 2 (the two-pass f16 type; round 6): O = PLAIN f16 rows - the A operand of the next dtype-4 launch (GEGLU -> ff-out). The
+        // launcher checked: no split-K, no residual / row biases, act 0 or GEGLU, stored columns % 8 == 0, 16-byte aligned rows. 8-byte
+        // vector stores through a buffer resource (a lane outside M x N offers an out-of-window offset), values clamped to the finite f16
+        // range with NaN kept (common.h pack4_f16_sat); p.sat_count (debug) counts the clamped lanes.
+        constexpr unsigned OOB2 = 0x80000000u;
+        auto uptr = [](const void* q) __attribute__((always_inline)) -> void* {
+            const unsigned long long v = (unsigned long long)q;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (void*)(((unsigned long long)hi << 32) | lo);
+        };
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+            uptr((unsigned short*)p.O + e_bz * p.o_bs + (long)m_w0 * p.ldo + (geglu ? (n_w0 >> 1) : n_w0)), 0, OOB2, 0x00020000);
+        const int nleft = p.N - n_w0;
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            uptr(p.bias ? (const void*)(p.bias + n_w0) : p.zeros), 0, (p.bias && nleft > 0) ? (unsigned)nleft * 4u : 0u, 0x00020000);
+        const unsigned offO = (unsigned)(lr * (int)p.ldo + 4 * lq) * 2u, rowO = (unsigned)p.ldo * 32u;       // bytes per 16-row block
+        if (geglu) {
+            if constexpr (NB % 4 == 0) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if ((b & 3) >= 2) continue;
+                    const bool grp = n_w0 + 16 * (b & ~3) + 64 <= p.N;       // whole 64-column value | gate groups only (N % 64 == 0)
+                    const u32x4 bv = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b, 0, 0);
+                    const u32x4 bg = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b + 128u, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MB; ++a) {
+                        const bool ok = grp && m_w0 + a * 16 + lr < p.M;
+                        float e[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            e[j] = (acc[a][b][j] * p.alpha + __uint_as_float(bv[j])) * gelu_erf_f(acc[a][b + 2 < NB ? b + 2 : b][j] * p.alpha + __uint_as_float(bg[j]));
+                        count_f16_saturation(p.sat_count, e);
+                        __builtin_amdgcn_raw_buffer_store_b64(pack4_f16_sat(e), rsO, (ok ? offO + a * rowO : OOB2) + (unsigned)(32 * (b >> 2) + 16 * (b & 1)) * 2u, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const bool colok = n_w0 + 16 * b + 4 * lq < p.N;
+                const u32x4 bcu = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(4 * lq) * 4u + 64u * b, 0, 0);
+#pragma unroll
+                for (int a = 0; a < MB; ++a) {
+                    const bool ok = colok && m_w0 + a * 16 + lr < p.M;
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = acc[a][b][j] * p.alpha + __uint_as_float(bcu[j]);
+                    count_f16_saturation(p.sat_count, e);
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4_f16_sat(e), rsO, (ok ? offO + a * rowO : OOB2) + 32u * b, 0, 0);
+                }
+            }
+        }
+        return;
+    }
     const bool wide = vec_ok && odt == GEO4D_F32;       // (o_split: N % 8 == 0, so the two lanes of an 8-column group are in range together)
     // Fast paths: every access goes through a raw buffer resource whose base is this wave's tile corner (wave-uniform, SGPRs): a lane
     // outside M x N offers an offset beyond the 2 GB window (stores dropped, loads return 0 - no exec-masked branches, so hipcc's
@@ -359,8 +407,7 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
                     }
                     const long oidx = obase + (long)m * ldo + oc;
                     if (vec_ok) {
-                        if constexpr (OSPLIT && OH) store_split4_f16((float*)O + obase + (long)m * ldo, oc >> 2, e);
-                        else if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
+                        if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, oc >> 2, e);
                         else if (odt == GEO4D_F32) *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
                         else if (odt == GEO4D_BF16) *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_bf16x2(e[0], e[1]), f32x2_to_bf16x2(e[2], e[3])};
                         else *(u32x2*)((unsigned short*)O + oidx) = u32x2{f32x2_to_f16x2(e[0], e[1]), f32x2_to_f16x2(e[2], e[3])};
@@ -400,8 +447,7 @@ __device__ __forceinline__ void reg_epilogue(const geo4d_conv_gemm_t& p, const f
 #pragma unroll
                         for (int j = 0; j < 4; ++j) e[j] += r[j];
                     }
-                    if constexpr (OSPLIT && OH) store_split4_f16((float*)O + obase + (long)m * ldo, n >> 2, e);
-                    else if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, n >> 2, e);     // (OSPLIT launches are never partial)
+                    if constexpr (OSPLIT) store_split4((float*)O + obase + (long)m * ldo, n >> 2, e);     // (OSPLIT launches are never partial)
                     else *(f32x4*)((float*)O + oidx) = f32x4{e[0], e[1], e[2], e[3]};
                 } else {
                     if (has_res) {
@@ -479,7 +525,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
     int cA[ACH], cB[BCH];                              // source-side swizzle: LDS slot `ccol` of panel row r holds chunk ccol ^ key(r)
 #pragma unroll
     for (int i = 0; i < ACH; ++i)
-        cA[i] = A64 ? ((tid & 3) ^ swz_key_a64(r0a + i * RSTEP_A)) * 2 * EPC      // K-group g: its hi chunk sits 32 bytes (8 elements) apart
+        cA[i] = A64 ? ((tid & 3) ^ swz_key_a64(r0a + i * RSTEP_A)) * 16           // BYTES: K-group g of the slab = 8 consecutive f16 of the plain f16 row
                     : (ccol ^ swz_key<T>(r0 + i * RSTEP)) * EPC;
 #pragma unroll
     for (int i = 0; i < BCH; ++i) cB[i] = (ccol ^ swz_key<T>(r0 + i * RSTEP)) * EPC;
@@ -501,7 +547,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         bz = rest % p.batch;
         kz = (int)(rest / p.batch);
         tile_of(t, tiles_n, tiles_mn, tile_group_m(p), tm, tn);
-        A = (const T*)p.A + bz * p.a_bs;
+        A = A64 ? (const T*)((const char*)p.A + bz * p.a_bs * 2) : (const T*)p.A + bz * p.a_bs;      // (A64: 2-byte elements)
         const T* __restrict__ W = (const T*)p.W + bz * p.w_bs;
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
@@ -545,7 +591,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         for (int j = 0; j < ACH; ++j) {
             // (A64: a wave's request covers 16 rows of 64 bytes - the same 1 KB at the same byte offsets, RSTEP * PITCH == RSTEP_A * 64)
             if ((ACH * RSTEP_A == BM) || (wave * (A64 ? 16 : 8) + j * RSTEP_A < BM)) {
-                const T* src = pix[j] >= 0 ? A + (long)pix[j] * p.lda + c0 + cA[j] : Z;
+                const T* src = pix[j] < 0 ? Z : A64 ? (const T*)((const char*)A + ((long)pix[j] * p.lda + c0) * 2 + cA[j]) : A + (long)pix[j] * p.lda + c0 + cA[j];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(base + j * RSTEP * PITCH), 16, 0, 0);
             }
@@ -581,7 +627,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_v2_kernel(const geo4d_
         const char* abase = smem + (buf * BM + wr * WTM) * PITCH;
         const char* bbase = smem + (2 * BM + buf * BN + wc * WTN) * PITCH;
         if constexpr (IsTwoPass<T>::value) {
-            // f16x2: pre-split operands only; the activation panel holds hi chunks only (A64). (Round 5 also built the form that converts a RAW f32
+            // f16x2: pre-split weights x plain f16 activation rows (A64 panel: 4 K-groups of 8 f16 per row). (Round 5 also built the form that converts a RAW f32
             // activation in registers - residual streams: down / up samplers, skip connections, proj_out, the VAE's upsamplers - and removed
             // it again: rounding a STREAM to f16 took the 50-step point-map drift from 1.1e-4 to 5.3e-4 for +1 % frames/s)
             u32x4 ah[MB];
@@ -716,6 +762,13 @@ inline bool o_split_ok(const geo4d_conv_gemm_t& p, int splits) {
            (p.batch == 1 || (p.o_bs & 7) == 0) && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R % 16) == 0 && (p.batch == 1 || (p.r_bs & 3) == 0)));
 }
 
+// o_split = 2 (the two-pass f16 type): plain f16 rows out - column bias + alpha (+ GEGLU) only, whole 8-column groups, 16-byte aligned rows
+inline bool o_f16_ok(const geo4d_conv_gemm_t& p, int splits) {
+    const long nout = p.act == 2 ? (p.N >> 1) : p.N;
+    return splits == 1 && p.w_split && p.a_split == 2 && (p.act == 0 || p.act == 2) && !p.R && !p.rowbias && !p.bias_per_row && (nout & 7) == 0 && (p.ldo & 7) == 0 &&
+           ((uintptr_t)p.O % 16) == 0 && (p.batch == 1 || (p.o_bs & 7) == 0);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     if (p.act == 2 && ((BN / WN / 16) % 4)) {
@@ -724,13 +777,13 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     }
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
     if constexpr (IsTwoPass<T>::value) {       // f16x2: pre-split x pre-split; plain f32 rows out, or (o_split = 2) the f16 pre-split format
-        if (!p.a_split || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands; o_split 0 or 2 (f16 halves)"); return GEO4D_EINVAL; }
+        if (p.a_split != 2 || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes plain f16 activation rows (a_split = 2) and a pre-split f16 weight; o_split 0 or 2 (plain f16 rows out)"); return GEO4D_EINVAL; }
         if (p.o_split) {
             // (the f16-halves epilogue exists on the GEGLU-capable tiles only: its one user is the GEGLU -> ff-out chain)
             if constexpr (((BN / WN / 16) % 4) == 0) {
-                if (o_split_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+                if (o_f16_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
             }
-            geo4d_set_error("conv_gemm: o_split = 2 needs a GEGLU-capable tile (wave tiles a multiple of 64 columns wide), no split-K, N % 8 == 0 and 32-byte aligned output rows");
+            geo4d_set_error("conv_gemm: o_split = 2 (plain f16 rows out) needs a GEGLU-capable tile (wave tiles a multiple of 64 columns wide), no split-K / residual / row biases / SiLU / GELU, stored columns % 8 == 0 and 16-byte aligned output rows");
             return GEO4D_EINVAL;
         }
         return launch_v2_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);

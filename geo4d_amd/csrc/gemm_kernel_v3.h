@@ -61,8 +61,9 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     constexpr int MB0 = (MB + 1) / 2, MB1 = MB - MB0, NB0 = (NB + 1) / 2, NB1 = NB - NB0;     // 16-blocks of R0 | R1, C0 | C1
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && MB1 >= 1 && NB1 >= 1, "wave tiles of at least 32 x 32");
     constexpr int RA0 = WM * MB0 * 16, RA1 = WM * MB1 * 16, RB0 = WN * NB0 * 16, RB1 = WN * NB1 * 16;   // rows of the half panels
-    // A64 (the two-pass f16 type, gemm_kernel_v2.h swz_key_a64): the activation panel holds only the hi chunks - rows of 64 bytes, 16 rows
-    // per 1 KB request, 128 rows per staging pass of the 8 waves: half the A-side LDS-DMA requests of a slab
+    // A64 (the two-pass f16 type, gemm_kernel_v2.h swz_key_a64): the activation is ONE f16 per element, stored as plain f16 rows (round 6) -
+    // panel rows of 64 bytes = 64 contiguous bytes of the source row, 16 rows per 1 KB request, 128 rows per staging pass of the 8 waves:
+    // half the A-side LDS-DMA requests of a slab
     constexpr bool A64 = IsTwoPass<T>::value;
     constexpr int PITCH_A = A64 ? PITCH_A64 : PITCH, RPA = A64 ? 128 : 64, RWA = A64 ? 16 : 8;          // A row pitch, rows per pass, rows per wave request
     constexpr int OA0 = 0, OA1 = RA0 * PITCH_A, OB0 = BM * PITCH, OB1 = (BM + RB0) * PITCH;             // their offsets in a stage
@@ -98,12 +99,13 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     // segment that followed it (profiles/r03_gemm_v3_timeline.md), i.e. the longest segment of the whole loop.
     constexpr unsigned OOB = 0x80000000u;              // = num_records of both resources
     constexpr int ESZ = 16 / EPC;                      // bytes per element (bf16x3 stores f32)
+    constexpr int ESZ_A = A64 ? 2 : ESZ;               // ... of the activation operand (A64: plain f16 rows)
     auto tile_row = [&](int r, int rows, int per_wave, int wt, int off) { return r < rows ? (r / per_wave) * wt + off + r % per_wave : -1; };
     auto rowA = [&](int h, int j) { return h ? tile_row(r0a + RPA * j, RA1, MB1 * 16, WTM, MB0 * 16) : tile_row(r0a + RPA * j, RA0, MB0 * 16, WTM, 0); };
     auto rowB = [&](int h, int j) { return h ? tile_row(r0 + 64 * j, RB1, NB1 * 16, WTN, NB0 * 16) : tile_row(r0 + 64 * j, RB0, NB0 * 16, WTN, 0); };
     auto chunk = [&](int j) { return (ccol ^ swz_key<T>(r0 + 64 * j)) * EPC; };   // LDS slot `ccol` of panel row r holds chunk ccol ^ key(r)
-    // A64: slot (tid & 3) of panel row r holds the hi chunk of K-group slot ^ key_a64(r); a group's hi chunk sits 32 bytes = 2 EPC elements apart
-    auto chunkA = [&](int j) { return A64 ? ((tid & 3) ^ swz_key_a64(r0a + RPA * j)) * 2 * EPC : chunk(j); };
+    // A64: slot (tid & 3) of panel row r holds K-group slot ^ key_a64(r) of the slab = 8 consecutive f16 (16 bytes) of the source row
+    auto chunkA = [&](int j) { return A64 ? ((tid & 3) ^ swz_key_a64(r0a + RPA * j)) * 8 : chunk(j); };
     const int khw = p.KH * p.KW;
 
     // staging cursors (two slabs ahead of the MFMAs, across tiles) and the tile they are in
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     // (readfirstlane: the values are wave-uniform, but after a tile switch they come out of VALU code (integer divisions), and a buffer
     // load whose SGPR offset operand sits in a VGPR is legalised with a waterfall loop around every piece)
     auto refresh_A = [&]() {
-        soffA = __builtin_amdgcn_readfirstlane((unsigned)((((long)ktA * p.Hin + kyA) * p.Win + kxA) * p.lda + c0A) * ESZ);
+        soffA = __builtin_amdgcn_readfirstlane((unsigned)((((long)ktA * p.Hin + kyA) * p.Win + kxA) * p.lda + c0A) * ESZ_A);
         bitA = __builtin_amdgcn_readfirstlane((unsigned)((ktA * p.KH + kyA) * p.KW + kxA));
     };
     auto refresh_B = [&]() { soffB = __builtin_amdgcn_readfirstlane((unsigned)(tapB * p.Cin + c0B) * ESZ); };
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
     };
     auto window_A = [&](bool valid, int tm_, long bz_) {
         const long P0 = valid ? tap0_pixel(tm_ * BM) : 0;
-        rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + bz_ * p.a_bs + P0 * p.lda), 0, OOB, 0x00020000);
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (bz_ * p.a_bs + P0 * p.lda) * ESZ_A), 0, OOB, 0x00020000);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(512) void conv_gemm_v3_kernel(const geo4d_conv_gemm
                     const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
                     const int iy0 = oy * p.stride - p.ph, ix0 = ox * p.stride - p.pw, ft = (f % p.T) - p.pt;
                     const long px0 = ((long)(f - p.pt) * p.Hin + iy0) * p.Win + ix0;
-                    off = (unsigned)(((px0 - P0) * p.lda + chunkA(j)) * ESZ);
+                    off = (unsigned)(((px0 - P0) * p.lda + chunkA(j)) * ESZ_A);
                     unsigned bit = 1;
                     for (int kt = 0; kt < p.KT; ++kt)
                         for (int ky = 0; ky < p.KH; ++ky)
@@ -508,12 +510,12 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     }
     if (p.o_split && !IsX3<T>::value) { geo4d_set_error("conv_gemm: o_split is a bf16x3 option"); return GEO4D_EINVAL; }
     if constexpr (IsTwoPass<T>::value) {
-        if (!p.a_split || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes pre-split operands; o_split 0 or 2 (f16 halves)"); return GEO4D_EINVAL; }
+        if (p.a_split != 2 || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes plain f16 activation rows (a_split = 2) and a pre-split f16 weight; o_split 0 or 2 (plain f16 rows out)"); return GEO4D_EINVAL; }
         if (p.o_split) {
             if constexpr (((BN / WN / 16) % 4) == 0) {
-                if (o_split_ok(p, splits)) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+                if (o_f16_ok(p, splits)) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
             }
-            geo4d_set_error("conv_gemm: o_split = 2 needs a GEGLU-capable tile (wave tiles a multiple of 64 columns wide), no split-K, N % 8 == 0 and 32-byte aligned output rows");
+            geo4d_set_error("conv_gemm: o_split = 2 (plain f16 rows out) needs a GEGLU-capable tile (wave tiles a multiple of 64 columns wide), no split-K / residual / row biases / SiLU / GELU, stored columns % 8 == 0 and 16-byte aligned output rows");
             return GEO4D_EINVAL;
         }
         return launch_v3_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);
@@ -555,9 +557,9 @@ bool v3_native(const geo4d_conv_gemm_t& p, int sp) {
     }
     // the staging side addresses each operand through a 2 GB buffer window per tile (see the kernel): nearest-upsampling gathers have
     // no uniform tap offsets, and a tile's rows plus its taps must stay inside the window
-    const long esz = 16 / Elem<T>::EPC;
+    const long esz = 16 / Elem<T>::EPC, esz_a = IsTwoPass<T>::value ? 2 : esz;
     const long frames = 256 / ((long)p.Hout * p.Wout) + 2 + p.KT;
-    const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
+    const bool window_ok = p.ups == 1 && frames * p.Hin * p.Win * p.lda * esz_a < (1L << 31) && (320L * p.ldw + p.K) * esz < (1L << 31);
     return !(nslab % sp || ((nslab / sp) & 1) || nslab / sp < 4 || !vec_ok || !window_ok);
 }
 // rows per gn_colsum entry of the launch `p` describes (tile_hint >= 21), 0 = this launch cannot emit the sums

@@ -184,10 +184,10 @@ __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __re
 
 // ---- GroupNorm pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU -----------------
 // st: (mean, rstd) per group of this frame's statistic (global memory or LDS)
-template <typename T, int SPLIT>      // SPLIT: 0 plain rows, 1 pre-split bf16 hi | lo (bf16x3 consumers), 2 pre-split f16 hi | lo (f16x2 consumers)
+template <typename T, int SPLIT>      // SPLIT: 0 plain rows, 1 pre-split bf16 hi | lo (bf16x3 consumers), 2 plain f16 rows from f32 input (f16x2 consumers; ldy in f16 elements)
 __device__ __forceinline__ void gn_apply_body(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                               int HW, int C, int G, int R, const float* st, const float* __restrict__ gamma,
-                                              const float* __restrict__ beta, int act, int chunk, int f) {
+                                              const float* __restrict__ beta, int act, int chunk, int f, unsigned long long* sat) {
     constexpr int EPC = Elem<T>::EPC;
     const int tid = threadIdx.x;
     const int CPR = C / EPC;
@@ -230,8 +230,10 @@ __device__ __forceinline__ void gn_apply_body(const T* __restrict__ x, long ldx,
                     e[j] = o;
                 }
                 if constexpr (SPLIT == 1) store_split4(yb + (long)ru * ldy, cc, e);          // (ldy counts K elements of 4 bytes, like ldx)
-                else if constexpr (SPLIT == 2) store_split4_f16(yb + (long)ru * ldy, cc, e);
-                else *(u32x4*)(yb + (long)ru * ldy + cc * EPC) = f32_to_chunk<T>(e);
+                else if constexpr (SPLIT == 2) {
+                    count_f16_saturation(sat, e);
+                    store4_f16((char*)y + ((long)f * HW + row0 + ru) * ldy * 2, cc, e);
+                } else *(u32x4*)(yb + (long)ru * ldy + cc * EPC) = f32_to_chunk<T>(e);
             }
         }
     }
@@ -240,15 +242,15 @@ template <typename T, int SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                        int HW, int C, int G, int fps, int R,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int act) {
+                                                       const float* __restrict__ beta, int act, unsigned long long* sat) {
     const int f = blockIdx.y;
-    gn_apply_body<T, SPLIT>(x, ldx, y, ldy, HW, C, G, R, stats + (long)(f / fps) * G * 2, gamma, beta, act, blockIdx.x, f);
+    gn_apply_body<T, SPLIT>(x, ldx, y, ldy, HW, C, G, R, stats + (long)(f / fps) * G * 2, gamma, beta, act, blockIdx.x, f, sat);
 }
 
 // ---- LayerNorm: one wave per row, row held in registers ------------------------------------
-template <typename T, int MAXC, int SPLIT = 0>  // MAXC = chunks per lane; SPLIT (f32 only): write a pre-split operand format (1: bf16 hi | lo, 2: f16 hi | lo)
+template <typename T, int MAXC, int SPLIT = 0>  // MAXC = chunks per lane; SPLIT (f32 only): 1 = write the pre-split bf16 hi | lo operand format, 2 = plain f16 rows (ldy in f16 elements)
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int M, int C,
-                                                 float eps, const float* __restrict__ gamma, const float* __restrict__ beta) {
+                                                 float eps, const float* __restrict__ gamma, const float* __restrict__ beta, unsigned long long* sat) {
     constexpr int EPC = Elem<T>::EPC;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -291,7 +293,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
                 o[j] = (e[i][j] - mean) * rstd * gamma[c] + beta[c];
             }
             if constexpr (SPLIT == 1) store_split4(y + row * ldy, cc, o);
-            else if constexpr (SPLIT == 2) store_split4_f16(y + row * ldy, cc, o);
+            else if constexpr (SPLIT == 2) {
+                count_f16_saturation(sat, o);
+                store4_f16((char*)y + row * ldy * 2, cc, o);
+            }
             else *(u32x4*)(y + row * ldy + cc * EPC) = f32_to_chunk<T>(o);
         }
     }
@@ -348,18 +353,18 @@ int groupnorm_typed(const geo4d_groupnorm_t& p, hipStream_t s) {
         GEO4D_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL((gn_apply_kernel<T, SPLIT>), dim3(nchunk, p.F), dim3(256), 0, s, (const T*)p.x, (long)p.ldx, (T*)p.y, (long)p.ldy, p.HW,
-                       p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act);
+                       p.C, p.groups, p.frames_per_stat, R, stats, p.gamma, p.beta, p.act, SPLIT == 2 ? p.sat_count : nullptr);
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;
 }
 
 template <typename T, int SPLIT = 0>
 int layernorm_typed(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* g, const float* b,
-                    hipStream_t s) {
+                    hipStream_t s, unsigned long long* sat = nullptr) {
     constexpr int EPC = Elem<T>::EPC;
     const int per_lane = (C / EPC + 63) / 64;
     const dim3 grid((M + 3) / 4);
-#define LN_LAUNCH(MC) hipLaunchKernelGGL((ln_kernel<T, MC, SPLIT>), grid, dim3(256), 0, s, (const T*)x, ldx, (T*)y, ldy, M, C, eps, g, b)
+#define LN_LAUNCH(MC) hipLaunchKernelGGL((ln_kernel<T, MC, SPLIT>), grid, dim3(256), 0, s, (const T*)x, ldx, (T*)y, ldy, M, C, eps, g, b, sat)
     if (per_lane <= 1) LN_LAUNCH(1);
     else if (per_lane <= 2) LN_LAUNCH(2);
     else if (per_lane <= 3) LN_LAUNCH(3);
@@ -389,7 +394,8 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
         return GEO4D_EINVAL;
     }
     if (p.frames_per_stat <= 0 || p.F % p.frames_per_stat) { geo4d_set_error("groupnorm: F % frames_per_stat"); return GEO4D_EINVAL; }
-    if ((p.ldx * esz) % 16 || (p.ldy * esz) % 16 || ((uintptr_t)p.x % 16) || ((uintptr_t)p.y % 16)) { geo4d_set_error("groupnorm: alignment"); return GEO4D_EINVAL; }
+    const int yesz = p.split_out == 2 ? 2 : esz;       // (split_out 2: f16 rows from f32 input)
+    if ((p.ldx * esz) % 16 || (p.ldy * yesz) % 16 || ((uintptr_t)p.x % 16) || ((uintptr_t)p.y % 16)) { geo4d_set_error("groupnorm: alignment"); return GEO4D_EINVAL; }
     if (p.workspace_bytes < geo4d_groupnorm_workspace(p.F, p.HW, p.groups, p.frames_per_stat)) { geo4d_set_error("groupnorm: workspace too small"); return GEO4D_EINVAL; }
     if (p.F > 65535) { geo4d_set_error("groupnorm: too many frames"); return GEO4D_EINVAL; }
     {
@@ -399,7 +405,7 @@ extern "C" int geo4d_groupnorm(const geo4d_groupnorm_t* pp, void* stream) {
             return GEO4D_EINVAL;
         }
     }
-    if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8) || p.split_out > 2 || p.split_out < 0)) { geo4d_set_error("groupnorm: split_out (1 = bf16 hi | lo, 2 = f16 hi | lo) is a producer format for f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
+    if (p.split_out && (p.dtype != GEO4D_F32 || (p.C % 8) || p.split_out > 2 || p.split_out < 0)) { geo4d_set_error("groupnorm: split_out (1 = bf16 hi | lo, 2 = plain f16 rows) is a producer format for f32 input, C % 8 == 0"); return GEO4D_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     switch (p.dtype) {
         case GEO4D_F32: return p.split_out == 2 ? groupnorm_typed<float, 2>(p, s) : p.split_out ? groupnorm_typed<float, 1>(p, s) : groupnorm_typed<float, 0>(p, s);
@@ -424,12 +430,12 @@ extern "C" int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M
 }
 
 extern "C" int geo4d_layernorm_split(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
-                                     const float* beta, int fmt, void* stream) {
-    if (M <= 0 || C <= 0 || C % 8 || (ldx * 4) % 16 || (ldy * 4) % 16 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16) || (fmt != 1 && fmt != 2)) {
-        geo4d_set_error("layernorm_split: bad arguments (f32 input, C % 8 == 0, 16-byte aligned rows, fmt 1 = bf16 halves or 2 = f16 halves)");
+                                     const float* beta, int fmt, unsigned long long* sat_count, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || (ldx * 4) % 16 || (ldy * (fmt == 2 ? 2 : 4)) % 16 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16) || (fmt != 1 && fmt != 2)) {
+        geo4d_set_error("layernorm_split: bad arguments (f32 input, C % 8 == 0, 16-byte aligned rows, fmt 1 = bf16 halves or 2 = plain f16 rows)");
         return GEO4D_EINVAL;
     }
-    if (fmt == 2) return layernorm_typed<float, 2>(x, ldx, y, ldy, M, C, eps, gamma, beta, (hipStream_t)stream);
+    if (fmt == 2) return layernorm_typed<float, 2>(x, ldx, y, ldy, M, C, eps, gamma, beta, (hipStream_t)stream, sat_count);
     return layernorm_typed<float, 1>(x, ldx, y, ldy, M, C, eps, gamma, beta, (hipStream_t)stream);
 }
 

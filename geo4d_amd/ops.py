@@ -29,19 +29,44 @@ def k_align(dtype):
     return 32 if _resolve_precision(dtype).storage == torch.float32 else 64
 
 
+class X2Weight(torch.Tensor):
+    """A pack.split_f16 weight: float16 [N, 2K] = f16 hi | lo per 8 K-elements of s * w, carrying alpha = 1 / s of its launch. A Tensor
+    subclass so that the scale travels with the data: .to() / .clone() / .detach() / .contiguous() and same-shape views keep it (a
+    plain attribute on a plain tensor was lost by all of them); slicing or reshaping gives a plain float16 tensor, which
+    conv_gemm refuses as a two-pass weight."""
+    _KEEP = {"to", "clone", "detach", "contiguous", "cuda", "cpu", "pin_memory"}
+
+    @staticmethod
+    def wrap(t, alpha):
+        r = t.as_subclass(X2Weight)
+        r._x2_alpha = float(alpha)
+        return r
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        if isinstance(out, X2Weight):
+            src = next((a for a in args if isinstance(a, X2Weight) and hasattr(a, "_x2_alpha")), None)
+            if src is not None and getattr(func, "__name__", "") in cls._KEEP and out.shape == src.shape and out.dtype == torch.float16:
+                out._x2_alpha = src._x2_alpha
+            elif not hasattr(out, "_x2_alpha"):
+                out = out.as_subclass(torch.Tensor)        # anything else is just a float16 matrix
+        return out
+
+
 def is_x2_weight(w):
-    """A pack.split_f16 weight (float16 [N, 2K] = f16 hi | lo per 8 K-elements, carrying the 1 / scale of its launch)."""
-    return w.dtype == torch.float16 and hasattr(w, "_x2_alpha")
+    """A pack.split_f16 weight (X2Weight: float16 [N, 2K] = f16 hi | lo per 8 K-elements, carrying the 1 / scale of its launch)."""
+    return isinstance(w, X2Weight) and w.dtype == torch.float16 and hasattr(w, "_x2_alpha")
 
 
 def is_split(w, other):
-    """True when `w` is a PRE-SPLIT operand (pack.split_bf16: bf16 [rows, 2K]; pack.split_f16: float16 [rows, 2K] of the two-pass f16
-    form) multiplied with a raw f32 operand."""
-    return (w.dtype == torch.bfloat16 or is_x2_weight(w)) and other.dtype == torch.float32
+    """True when `w` is a PRE-SPLIT bf16x3 operand (pack.split_bf16: bf16 [rows, 2K]) multiplied with a raw f32 operand."""
+    return w.dtype == torch.bfloat16 and other.dtype == torch.float32
 
 
 class SplitAct(torch.Tensor):
-    """A bf16 [rows, 2K] activation in the pre-split bf16x3 operand format (per 8 K-elements: 8 x bf16 hi | 8 x bf16 lo), written by
+    """(The two-pass f16 consumers take PLAIN float16 rows since round 6 - an ordinary tensor, no wrapper: new_split(fmt="f16").)
+    A bf16 [rows, 2K] activation in the pre-split bf16x3 operand format (per 8 K-elements: 8 x bf16 hi | 8 x bf16 lo), written by
     the producers that feed GEMMs (GroupNorm / LayerNorm / attention / GEGLU epilogue with split_out) so that conv_gemm does not
     split the fragments again in its K loop. A Tensor subclass only to make the format visible to conv_gemm; every other entry point
     of this module rejects it (`_dev`), and producers require a whole contiguous matrix as their split output (`_split_out_ok`).
@@ -52,9 +77,12 @@ class SplitAct(torch.Tensor):
 
 
 def new_split(rows, k, device, fmt="bf16"):
-    """`fmt`: "bf16" = the bf16x3 operand format; "f16" = the two-pass f16 format (dtype 4: [8 x f16 hi | 8 x f16 lo], consumed by
-    conv_gemm against a pack.split_f16 weight). The torch dtype of the buffer names the format."""
-    return SplitAct.wrap(torch.empty((rows, 2 * k), device=device, dtype=torch.float16 if fmt == "f16" else torch.bfloat16))
+    """The A operand a producer writes for the GEMM that follows. `fmt`: "bf16" = the pre-split bf16x3 operand format (SplitAct, bf16
+    [rows, 2k]); "f16" = the two-pass f16 consumers' operand (dtype 4): PLAIN float16 rows [rows, k] - the activation is multiplied as
+    one f16, so since round 6 nothing else is stored (round 5 wrote an f16 lo half beside it that no kernel read)."""
+    if fmt == "f16":
+        return torch.empty((rows, k), device=device, dtype=torch.float16)
+    return SplitAct.wrap(torch.empty((rows, 2 * k), device=device, dtype=torch.bfloat16))
 
 
 def split_fmt(split_out):
@@ -74,8 +102,8 @@ def act_k(x):
 
 
 def kdim(w, other):
-    """Logical K extent of a 2-D operand (a pre-split operand stores 2 bf16 per K element)."""
-    return w.shape[1] // 2 if (is_split(w, other) or isinstance(other, SplitAct)) else w.shape[1]
+    """Logical K extent of a 2-D operand (a pre-split operand stores 2 bf16 / f16 per K element)."""
+    return w.shape[1] // 2 if (is_split(w, other) or isinstance(other, SplitAct) or is_x2_weight(w)) else w.shape[1]
 
 
 def _stream():
@@ -160,6 +188,8 @@ TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) o
 DEBUG_ABLATE = _env_level("GEO4D_DEBUG_ABLATE", 0)       # tests / A-B runs: 2 = three persistent workgroups; 16 + g = tile order with GROUP_M = g (17 = column-fastest)
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end, MFMA passes per product)
 ATTN_TIMELINE = None   # the same for the spatial self-attention launches (one key/value set) of ops.attention
+SAT_COUNTER = None     # debug: an int64 [1] device tensor -> every f16-clamping store (GroupNorm / LayerNorm / GEGLU epilogue writing the two-pass
+                       # GEMM's f16 operand) adds the lanes it clamped (|x| > 65504); tests assert 0 at full size. None in production.
 
 
 def _tune_table():
@@ -241,23 +271,24 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     if isinstance(out, SplitAct) and batch == 1:
         _split_out_ok(out, M)
     a_split, w_split = is_split(a, w), is_split(w, a)
-    if isinstance(a, SplitAct) and a.dtype == torch.float16:
-        # two-pass f16 (dtype 4): a GroupNorm output in the f16 pre-split format x a pack.split_f16 weight (which carries its 1 / scale)
-        assert w.dtype == torch.float16 and hasattr(w, "_x2_alpha"), "an f16 SplitAct multiplies a pack.split_f16 weight"
-        assert (out.dtype == torch.float16 if isinstance(out, SplitAct) else out.dtype == torch.float32) and not out_nchw, \
-            "the two-pass f16 GEMM writes plain f32 rows or the f16 pre-split format"
-        assert lda % 2 == 0 and ldw % 2 == 0 and a_bs % 2 == 0 and w_bs % 2 == 0
-        a_split = w_split = True
+    assert not is_x2_weight(a), "a pack.split_f16 weight is the W operand"
+    x2 = is_x2_weight(w)
+    if x2 or (a.dtype == torch.float16 and w.dtype == torch.float16 and isinstance(w, X2Weight)):
+        # two-pass f16 (dtype 4): plain f16 activation rows (GroupNorm / LayerNorm / GEGLU-epilogue output) x a pack.split_f16 weight (which carries its 1 / scale)
+        assert x2, "a two-pass weight lost its scale (sliced / reshaped X2Weight?)"
+        assert a.dtype == torch.float16 and not isinstance(a, SplitAct), "a pack.split_f16 weight multiplies plain float16 activation rows (the two-pass form has no raw-f32 launch)"
+        assert out.dtype in (torch.float16, torch.float32) and not isinstance(out, SplitAct) and not out_nchw, "the two-pass f16 GEMM writes plain f32 rows or plain f16 rows"
+        assert ldw % 2 == 0 and w_bs % 2 == 0
+        a_split, w_split = 2, True
         code = F16X2
         alpha = alpha * w._x2_alpha
-        lda, a_bs, ldw, w_bs = lda // 2, a_bs // 2, ldw // 2, w_bs // 2
+        ldw, w_bs = ldw // 2, w_bs // 2
     elif isinstance(a, SplitAct) or isinstance(w, SplitAct):     # pre-split activations x pre-split weights (bf16 storage, 4 bytes per K element)
         assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and lda % 2 == 0 and ldw % 2 == 0 and a_bs % 2 == 0 and w_bs % 2 == 0
         a_split = w_split = True
         code = BF16X3
         lda, a_bs, ldw, w_bs = lda // 2, a_bs // 2, ldw // 2, w_bs // 2
     elif a_split or w_split:
-        assert not (is_x2_weight(w) or is_x2_weight(a)), "a pack.split_f16 weight multiplies an f16 SplitAct (the two-pass form has no raw-activation launch)"
         code = BF16X3
         if a_split:
             assert lda % 2 == 0 and a_bs % 2 == 0
@@ -287,16 +318,19 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     p.T, p.Hin, p.Win, p.Hout, p.Wout = T, Hin, Win, Hout, Wout
     p.KT, p.KH, p.KW, p.pt, p.ph, p.pw, p.stride, p.ups = KT, KH, KW, pt, ph, pw, stride, ups
     p.rowbias_div, p.bias_per_row, p.act = rowbias_div, int(bias_per_row), act
-    p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = code, dt_code(out.dtype), int(out_nchw), tile_hint
+    p.dtype, p.out_dtype, p.out_nchw, p.tile_hint = code, (F32 if code == F16X2 else dt_code(out.dtype)), int(out_nchw), tile_hint
     p.alpha, p.split_k = alpha, split_k
     p.debug_ablate = DEBUG_ABLATE
     p.a_split, p.w_split = int(a_split), int(w_split)
-    p.o_split = (2 if out.dtype == torch.float16 else 1) if isinstance(out, SplitAct) else 0
-    if p.o_split:
-        assert (code == BF16X3 and p.o_split == 1) or (code == F16X2 and p.o_split == 2), "pre-split outputs: bf16 halves from bf16x3 launches, f16 halves from two-pass f16 launches"
+    p.o_split = 1 if isinstance(out, SplitAct) else 2 if (code == F16X2 and out.dtype == torch.float16) else 0
+    if p.o_split == 1:
+        assert code == BF16X3, "pre-split (bf16 hi | lo) outputs come from bf16x3 launches"
         assert ldo % 2 == 0 and o_bs % 2 == 0
         p.ldo, p.o_bs, p.out_dtype = ldo // 2, o_bs // 2, F32
+    elif p.o_split == 2:            # plain f16 rows (clamped): ldo / o_bs stay in f16 elements
+        assert residual is None and rowbias is None and not bias_per_row and act in (0, 2), "the f16-row epilogue of the two-pass GEMM: column bias (+ GEGLU) only"
     p.gn_colsum = 0
+    p.sat_count = _ptr(SAT_COUNTER) if p.o_split == 2 else 0
     ws, zeros = workspace(a.device)
     p.workspace, p.workspace_bytes, p.zeros = ws.data_ptr(), ws.numel(), zeros.data_ptr()
 
@@ -307,7 +341,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     if tile_hint == 0 and split_k == 0:
         key = f"{p.dtype}/{p.out_dtype}|{M}x{N}x{K}|c{Cin}|t{KT}{KH}{KW}s{stride}u{ups}|a{act}r{int(residual is not None)}n{int(out_nchw)}|b{batch}"
         if code in (BF16X3, F16X2):
-            key += f"|x{int(a_split)}{int(w_split)}" + ("o" if p.o_split else "")       # (dtype 4's "o" = its f16 halves)
+            key += f"|x{int(bool(a_split))}{int(w_split)}" + ("o" if p.o_split else "")       # (dtype 4's "o" = its f16 rows)
         cfg = _tune_table().get(key)
         if cfg is None and code == BF16X3 and a_split and w_split:
             # pre-split activations: same tile geometry as the raw-activation launch of the same shape (table measured on those)
@@ -358,8 +392,9 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
     return out
 
 
-def _out_dtype(x, out_dtype):
-    return out_dtype or (torch.float32 if isinstance(x, SplitAct) else x.dtype)
+def _out_dtype(x, out_dtype, w=None):
+    """Default output dtype of a GEMM: f32 rows for the 4-byte modes' operand formats (a SplitAct, or f16 rows against a two-pass weight)."""
+    return out_dtype or (torch.float32 if (isinstance(x, SplitAct) or (w is not None and is_x2_weight(w))) else x.dtype)
 
 
 def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, alpha=1.0, tile_hint=0, split_k=0, gn_stats=False,
@@ -371,7 +406,7 @@ def linear(x, w, bias=None, *, residual=None, act=0, out=None, out_dtype=None, a
     assert kdim(w, x) == K, (w.shape, x.shape)
     if out is None:
         nout = N // 2 if act == 2 else N
-        out = new_split(M, nout, x.device, split_fmt(split_out)[1]) if split_out else torch.empty((M, nout), device=x.device, dtype=_out_dtype(x, out_dtype))
+        out = new_split(M, nout, x.device, split_fmt(split_out)[1]) if split_out else torch.empty((M, nout), device=x.device, dtype=_out_dtype(x, out_dtype, w))
     return conv_gemm(x, w, out, M=M, N=N, K=K, Cin=K, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), bias=bias,
                      residual=residual, ldr=_ld(residual) if residual is not None else 0, act=act, alpha=alpha,
                      tile_hint=tile_hint, split_k=split_k, gn_stats=gn_stats)
@@ -395,7 +430,7 @@ def conv2d(x, w, bias, *, F, Hin, Win, KH, KW, stride=1, pad=0, pad_end=0, ups=1
         if out_nchw:
             out = torch.empty((F // T, N, T, Hout, Wout), device=x.device, dtype=out_dtype or torch.float32)
         else:
-            out = torch.empty((M, N), device=x.device, dtype=_out_dtype(x, out_dtype))
+            out = torch.empty((M, N), device=x.device, dtype=_out_dtype(x, out_dtype, w))
     conv_gemm(x, w, out, M=M, N=N, K=KH * KW * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=(nchw_channels or N) if out_nchw else _ld(out), T=T,
               Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=KH, KW=KW, ph=pad, pw=pad, stride=stride, ups=ups, bias=bias,
               rowbias=rowbias, rowbias_div=rowbias_div, residual=residual,
@@ -411,7 +446,7 @@ def conv_temporal(x, w, bias, *, B, T, HW, residual=None, out=None, gn_stats=Fal
     M = B * T * HW
     assert x.shape[0] == M and kdim(w, x) == 3 * Cin
     if out is None:
-        out = torch.empty((M, N), device=x.device, dtype=_out_dtype(x, None))
+        out = torch.empty((M, N), device=x.device, dtype=_out_dtype(x, None, w))
     return conv_gemm(x, w, out, M=M, N=N, K=3 * Cin, Cin=Cin, lda=_ld(x), ldw=_ld(w), ldo=_ld(out), T=T, Hin=HW, Win=1,
                      Hout=HW, Wout=1, KT=3, pt=1, bias=bias, residual=residual,
                      ldr=_ld(residual) if residual is not None else 0, gn_stats=gn_stats, tile_hint=tile_hint, split_k=split_k)
@@ -438,17 +473,19 @@ def groupnorm(x, gamma, beta, *, F, HW, eps, groups=32, frames_per_stat=1, silu=
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
     if out is None:
         out = new_split(F * HW, Cc, x.device, split_fmt(split_out)[1]) if split_out else torch.empty((F * HW, Cc), device=x.device, dtype=x.dtype)
-    split_out = (2 if out.dtype == torch.float16 else 1) if isinstance(out, SplitAct) else 0
+    split_out = 1 if isinstance(out, SplitAct) else 2 if (out.dtype == torch.float16 and x.dtype == torch.float32) else 0
     if split_out:
-        assert x.dtype == torch.float32, "the pre-split producer formats are written from f32 activations"
+        assert x.dtype == torch.float32, "the GEMM-operand producer formats are written from f32 activations"
+    if split_out == 1:
         _split_out_ok(out, F * HW)
     need = lib.geo4d_groupnorm_workspace(F, HW, groups, frames_per_stat)
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     p = GroupNorm()
     p.x, p.y, p.gamma, p.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
     p.workspace, p.workspace_bytes = ws.data_ptr(), need
-    p.ldx, p.ldy = _ld(x), (_ld(out) // 2 if split_out else _ld(out))
+    p.ldx, p.ldy = _ld(x), (_ld(out) // 2 if split_out == 1 else _ld(out))
     p.split_out = int(split_out)
+    p.sat_count = _ptr(SAT_COUNTER) if split_out == 2 else 0
     p.F, p.HW, p.C, p.groups, p.frames_per_stat = F, HW, Cc, groups, frames_per_stat
     p.act, p.dtype, p.eps = int(silu), dt_code(x.dtype), eps
     cs = getattr(x, "_gn_colsum", None)     # column sums left on this very tensor object by the GEMM that produced it
@@ -466,13 +503,18 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, split_out=False):
     _dev(x, "x")
     assert not isinstance(x, SplitAct), "LayerNorm reads plain activations"
     M, Cc = x.shape
-    if split_out or isinstance(out, SplitAct):
+    if split_out or isinstance(out, SplitAct) or (out is not None and out.dtype == torch.float16 and x.dtype == torch.float32):
         assert x.dtype == torch.float32
         if out is None:
             out = new_split(M, Cc, x.device, split_fmt(split_out)[1])
-        _split_out_ok(out, M)
-        _lib.check(lib.geo4d_layernorm_split(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out) // 2, M, Cc, eps, gamma.data_ptr(),
-                                             beta.data_ptr(), 2 if out.dtype == torch.float16 else 1, _stream()), "geo4d_layernorm_split")
+        if isinstance(out, SplitAct):
+            _split_out_ok(out, M)
+            _lib.check(lib.geo4d_layernorm_split(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out) // 2, M, Cc, eps, gamma.data_ptr(),
+                                                 beta.data_ptr(), 1, 0, _stream()), "geo4d_layernorm_split")
+        else:           # plain f16 rows: the two-pass GEMM's A operand
+            assert out.dtype == torch.float16
+            _lib.check(lib.geo4d_layernorm_split(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), M, Cc, eps, gamma.data_ptr(),
+                                                 beta.data_ptr(), 2, _ptr(SAT_COUNTER), _stream()), "geo4d_layernorm_split")
         return out
     if out is None:
         out = torch.empty((M, Cc), device=x.device, dtype=x.dtype)

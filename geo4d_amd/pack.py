@@ -5,7 +5,7 @@ GEGLU projections get their value/gate rows interleaved in blocks of 32 so the G
 """
 import torch
 
-from .ops import k_align
+from .ops import X2Weight, k_align
 from .precision import resolve
 
 
@@ -24,7 +24,11 @@ def split_f16(w):
     """[N, K] fp32 (K % 8 == 0) -> the pre-split weight of the two-pass f16 GEMM (include/geo4d_hip.h dtype 4): a float16 tensor
     [N, 2K] holding, per 8 K-elements, [8 x hi | 8 x lo] with hi = f16(s w), lo = f16(s w - hi) and s a power of two that puts the
     largest |w| at 2^13..2^14 (hi well inside the f16 range, lo of every weight that matters a NORMAL f16 number: hi + lo then carries
-    ~22 bits). The launch multiplies its accumulators by 1 / s (`_x2_alpha`, exact), before bias / residual."""
+    ~22 bits). The launch multiplies its accumulators by 1 / s (`X2Weight._x2_alpha`, exact), before bias / residual.
+    One scale per TENSOR is enough (ADVICE r5 asked for one per output row): a weight far below the tensor's largest one has a SUBNORMAL
+    lo half, whose absolute spacing is 2^-24 of the scaled range - hi + lo then carries an absolute error <= 2^-38 |w|_max, i.e. full
+    22-bit relative precision for every |w| >= 2^-16 |w|_max and an error of 2^-38 |w|_max below that: against a row whose rms is even
+    1000x below its outlier that is 2^-28 of the row's contribution (tests/test_f16x2_gpu.py::test_outlier_heavy_weights)."""
     n, k = w.shape
     assert k % 8 == 0
     w = w.float()
@@ -35,8 +39,7 @@ def split_f16(w):
     hi = ws.to(torch.float16)
     lo = (ws - hi.float()).to(torch.float16)
     out = torch.stack([hi.reshape(n, k // 8, 8), lo.reshape(n, k // 8, 8)], dim=2).reshape(n, 2 * k).contiguous()
-    out._x2_alpha = 2.0 ** -e
-    return out
+    return X2Weight.wrap(out, 2.0 ** -e)
 
 
 def pack_conv2d_x2(w, dtype, cin_pad=None):

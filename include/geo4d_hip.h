@@ -13,10 +13,11 @@
  *     3 = bf16x3 (conv_gemm / attention only): operands are f32 in memory (4 bytes per element, `ld*` in elements) and
  *     are multiplied as bf16 hi + bf16 lo with three bf16 MFMAs per product (~16 mantissa bits at 1/3 of the bf16
  *     rate instead of 1/16 for f32 MFMA) — the mode that meets the 1e-3 parity bar; every other entry point takes 0 for it;
- *     4 = f16x2 (conv_gemm only, round 5): both operands PRE-SPLIT as [8 x f16 hi | 8 x f16 lo] per 8 K-elements (the bf16x3
- *     pre-split layout with f16 halves; 4 bytes per element, `ld*` in elements); the product is a_hi.w_hi + a_hi.w_lo — TWO f16
- *     MFMAs: the activation carries 11 mantissa bits, the weight ~22. Used for the long-K 3x3 convolutions of the "bf16x3m" mode
- *     (tests/precision_sim.py: the point map stays < 3e-4 where a full f16 pass costs 2e-3); tile hints 0 or >= 22, f32 rows out;
+ *     4 = f16x2 (conv_gemm only, round 5; operand layout of round 6 = ABI 8): W PRE-SPLIT as [8 x f16 hi | 8 x f16 lo] per 8
+ *     K-elements (4 bytes per element, `ldw` / `w_bs` in elements), A = PLAIN f16 rows (2 bytes per element, `lda` / `a_bs` in f16
+ *     elements; a_split must be 2); the product is a.w_hi + a.w_lo — TWO f16 MFMAs: the activation carries 11 mantissa bits, the
+ *     weight ~22. Used for the GEMMs of the "bf16x3m" mode whose A operand is a normalised branch activation (DESIGN.md section 3;
+ *     tests/precision_sim.py); tile hints 0 or >= 22; f32 rows out, or (o_split = 2) plain f16 rows = the next dtype-4 launch's A;
  *   - every row pitch / base pointer must be 16-byte aligned (kernels move 16-byte chunks);
  *   - return 0 on success, negative errno-style code otherwise (-22 EINVAL, -95 ENOTSUP, -5 EIO = HIP launch
  *     error); geo4d_last_error() returns a thread-local message. Kernels never abort().
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GEO4D_ABI_VERSION 7
+#define GEO4D_ABI_VERSION 8
 
 /* Implicit-GEMM convolution / linear / batched GEMM:  out = epilogue(alpha * gather(A) . W^T)
  * replaces F.linear (attention.py:52-56,420,437), F.conv2d 3x3/1x1 stride 1|2 (openaimodel3d.py:154,179,65-67;
@@ -78,10 +79,12 @@ typedef struct geo4d_conv_gemm_t {
                             fastest instead of the column-fastest default (-9 % L2-miss fetch, -0.3 % frames/s: profiles/r05_tile_order.md) */
     float alpha;
     int a_split, w_split;/* dtype 3 (bf16x3): the operand is stored PRE-SPLIT, per 8 K-elements
-                            [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32; dtype 4 (f16x2): both must
-                            be set (f16 halves: pack.py split_f16 for weights, geo4d_groupnorm_t.split_out = 2 for activations) */
-    int o_split;         /* 2 (dtype 4 only): the same with f16 halves (values clamped to the f16 range) - the A operand of a following dtype-4
-                            launch (GEGLU -> FF-out). 1: dtype 3 (bf16x3), a_split and w_split set, out_dtype F32: O is written in the pre-split operand
+                            [8 x bf16 hi | 8 x bf16 lo] (32 bytes, pack.py split_bf16) instead of 8 raw f32; dtype 4 (f16x2): w_split = 1
+                            (f16 halves: pack.py split_f16) and a_split = 2 = A is plain f16 rows (geo4d_groupnorm_t.split_out = 2,
+                            geo4d_layernorm_split fmt 2, o_split = 2 of a previous dtype-4 launch) */
+    int o_split;         /* 2 (dtype 4 only; out_dtype F32, no residual, no split-K): O is written as PLAIN f16 rows (ldo / o_bs in f16 elements,
+                            stored columns % 8 == 0, 16-byte aligned rows), values clamped to the finite f16 range, NaN kept - the A operand of a following
+                            dtype-4 launch (GEGLU -> FF-out). 1: dtype 3 (bf16x3), a_split and w_split set, out_dtype F32: O is written in the pre-split operand
                             format ([8 x bf16 hi | 8 x bf16 lo] per 8 output columns; ldo / o_bs still count columns) - the producer
                             side of a_split (GEGLU -> FF-out chain; q | k and V^T of the spatial attention, geo4d_attention_t.qkv_split).
                             Stored columns % 8 == 0, ldo % 8 == 0, 32-byte aligned rows, no split-K, any epilogue incl. residual;
@@ -90,6 +93,8 @@ typedef struct geo4d_conv_gemm_t {
                             launch stores - the statistics pass of the GroupNorm that consumes O, produced for free by the epilogue
                             (geo4d_groupnorm_t.colsum). Needs M % 32 == 0, N % 8 == 0, row-major 16-byte aligned output, batch 1,
                             no GEGLU and no split-K. */
+    unsigned long long* sat_count; /* optional DEBUG counter in device memory (NULL in production): o_split = 2 launches add the number of
+                            (wave, store) lanes whose value lay beyond the finite f16 range and was clamped. Tests assert it stays 0. */
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);
 /* Rows of the output that ONE gn_colsum entry of the launch `*p` describes covers (tile_hint / split_k as they will be launched, the
@@ -111,11 +116,12 @@ typedef struct geo4d_groupnorm_t {
     float eps;
     const float* colsum; /* optional: [F*HW/colsum_rows][C][2] column sums written by the producing geo4d_conv_gemm (gn_colsum); when
                             given the pass over x that computes the statistics is skipped */
-    int split_out;       /* producers of GEMM operands (dtype F32 only, C % 8 == 0): y is written in the PRE-SPLIT operand format of
-                            geo4d_conv_gemm_t.a_split - 1: per 8 channels [8 x bf16 hi | 8 x bf16 lo] (bf16x3 consumers); 2: [8 x f16 hi |
-                            8 x f16 lo], values clamped to the f16 range (f16x2 consumers, dtype 4); ldy still counts channels */
+    int split_out;       /* producers of GEMM operands (dtype F32 only, C % 8 == 0): 1: y is written in the PRE-SPLIT operand format of
+                            geo4d_conv_gemm_t.a_split, per 8 channels [8 x bf16 hi | 8 x bf16 lo] (bf16x3 consumers; ldy counts channels = 4-byte
+                            units); 2: y = PLAIN f16 rows (ldy in f16 elements), values clamped to the finite f16 range, NaN kept (dtype-4 consumers) */
     int colsum_rows;     /* rows per `colsum` entry (what geo4d_conv_gemm_colsum_rows returned for the producing launch); 0 = 32;
                             (frames_per_stat x HW) % colsum_rows == 0 */
+    unsigned long long* sat_count; /* optional DEBUG counter (see geo4d_conv_gemm_t.sat_count) of the split_out = 2 clamp; NULL in production */
 } geo4d_groupnorm_t;
 size_t geo4d_groupnorm_workspace(int F, int HW, int groups, int frames_per_stat);
 int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);
@@ -124,10 +130,10 @@ int geo4d_groupnorm(const geo4d_groupnorm_t* p, void* stream);
 int geo4d_layernorm(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
                     const float* beta, int dtype, void* stream);
 
-/* the same for an f32 x, writing y in a pre-split operand format (geo4d_groupnorm_t.split_out: fmt 1 = bf16 hi | lo, 2 = f16 hi | lo);
- * C % 8 == 0. */
+/* the same for an f32 x, writing y in a GEMM-operand format (geo4d_groupnorm_t.split_out: fmt 1 = pre-split bf16 hi | lo, ldy in
+ * 4-byte units; fmt 2 = plain f16 rows, ldy in f16 elements, clamped, `sat_count` = optional debug counter of the clamp or NULL); C % 8 == 0. */
 int geo4d_layernorm_split(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* gamma,
-                          const float* beta, int fmt, void* stream);
+                          const float* beta, int fmt, unsigned long long* sat_count, void* stream);
 
 /* y = softmax(scale * x) per row, x fp32; replaces F.softmax in the VAE AttnBlock (ae_modules.py:66-68). */
 int geo4d_softmax_rows(const float* x, long ldx, void* y, long ldy, long rows, int cols, float scale, int out_dtype,

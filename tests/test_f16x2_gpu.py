@@ -1,5 +1,6 @@
-"""The two-pass f16 GEMM of the bf16x3m mode (include/geo4d_hip.h dtype 4, round 5): pre-split [8 x f16 hi | 8 x f16 lo] operands,
-product = a_hi.w_hi + a_hi.w_lo on the second- / third-generation tiles, and its producer (GroupNorm with split_out = "f16").
+"""The two-pass f16 GEMM of the bf16x3m mode (include/geo4d_hip.h dtype 4, round 5; operand layout of round 6): a pre-split
+[8 x f16 hi | 8 x f16 lo] weight x PLAIN f16 activation rows, product = a.w_hi + a.w_lo on the second- / third-generation tiles, and its
+producers (GroupNorm / LayerNorm / the GEGLU epilogue with split_out = "f16": plain f16 rows, clamped, NaN kept).
 
 What is checked is the ARITHMETIC THE MODE CLAIMS, not a loose tolerance: the reference is PyTorch fp64 math on exactly the operands the
 kernel multiplies - the activation rounded to f16, the weight as (f16 hi + f16 lo) / scale - so the only difference left is the fp32
@@ -20,13 +21,9 @@ V3_TILES = [71, 72, 73, 74]
 
 
 def split_f16_act(x):
-    """Host twin of store_split4_f16 (common.h): f32 [M, K] -> float16 [M, 2K], per 8 elements [8 x hi | 8 x lo]."""
-    from geo4d_amd import ops
-    m, k = x.shape
-    c = x.float().clamp(-65504.0, 65504.0)
-    hi = c.to(torch.float16)
-    lo = (c - hi.float()).to(torch.float16)
-    return ops.SplitAct.wrap(torch.stack([hi.reshape(m, k // 8, 8), lo.reshape(m, k // 8, 8)], dim=2).reshape(m, 2 * k).contiguous())
+    """Host twin of store4_f16 (common.h): f32 [M, K] -> the two-pass GEMM's A operand = plain float16 rows [M, K], clamped to the finite
+    f16 range (round 5 stored [8 x hi | 8 x lo] groups whose lo half no kernel read; hi is exactly this value)."""
+    return x.float().clamp(-65504.0, 65504.0).to(torch.float16).contiguous()
 
 
 def weight_seen(wp):
@@ -116,9 +113,89 @@ def test_default_tile_and_fallbacks(dev):
     with pytest.raises(RuntimeError):
         ops.linear(xs, wp, b, tile_hint=1, split_k=1)
     with pytest.raises(AssertionError):
-        ops.linear(xs, wp, b, split_out=True)                       # the two-pass GEMM writes plain f32 rows
+        ops.linear(xs, wp, b, split_out=True)                       # the two-pass GEMM writes plain f32 or plain f16 rows
     with pytest.raises(AssertionError):
         ops.linear(xs, pack.split_bf16(w), b)                       # an f16 activation needs an f16-split weight
+    with pytest.raises(AssertionError):
+        ops.linear(x, wp, b)                                        # ... and an f16-split weight an f16 activation (no raw-f32 launch)
+    # a non-GEGLU launch writing f16 rows (o_split = 2) with the library's own tile choice, M >= 4096 (the default used to
+    # pick the 160x320 tile, which has no f16-row epilogue -> EINVAL)
+    big = rnd((4608, 1024), dev, 33)
+    old = ops.AUTOTUNE
+    try:
+        ops.AUTOTUNE = False
+        ops._tune_table().pop("4/0|4608x128x1024|c1024|t111s1u1|a0r0n0|b1|x11o", None)
+        g = ops.linear(split_f16_act(big), wp, b, split_out="f16")
+    finally:
+        ops.AUTOTUNE = old
+    assert g.dtype == torch.float16 and g.shape == (4608, N)
+    want = (a_seen(big) @ weight_seen(wp).t() + b.double())
+    assert bool(((g.double() - want).abs() <= want.abs() * 2.0 ** -11 + 1e-5 * float(want.abs().max())).all())
+
+
+def test_saturation_counter_and_nan_propagation(dev):
+    """The f16-clamping stores (GroupNorm / LayerNorm / GEGLU epilogue writing the two-pass GEMM's operand): values beyond +-65504 are clamped AND
+    counted when ops.SAT_COUNTER is set (the full-size tests assert the count stays 0); a NaN stays a NaN (fminf(fmaxf()) laundered it
+    into -65504, hiding a diverged activation from every isfinite check downstream)."""
+    from geo4d_amd import ops, pack
+    M, C = 256, 64
+    x = rnd((M, C), dev, 90)
+    x[3, 5], x[7, 9], x[100, 1] = 3.0e6, -4.0e6, float("nan")          # LayerNorm of a row with one 3e6 entry: ~8 x gamma, so scale gamma up
+    gamma, beta = torch.full((C,), 3.0e4, device=dev), torch.zeros((C,), device=dev)
+    cnt = torch.zeros(1, device=dev, dtype=torch.int64)
+    old = ops.SAT_COUNTER
+    try:
+        ops.SAT_COUNTER = cnt
+        y = ops.layernorm(x, gamma, beta, split_out="f16")
+        n_ln = int(cnt.item())
+        plain = ops.layernorm(x, gamma, beta)
+        assert torch.isnan(plain[100]).all() and torch.isnan(y[100].float()).all(), "NaN must survive the clamp"
+        big = plain.abs() > 65504.0
+        assert big.any() and n_ln >= 1 and bool((y.float().abs()[big] == 65504.0).all()) and torch.isfinite(y[:100].float()).all()
+        # GroupNorm: one frame, gamma large -> saturates; counter moves on
+        g = ops.groupnorm(x[:100].contiguous(), gamma[:C], beta[:C], F=1, HW=100, eps=1e-5, groups=32, split_out="f16")
+        assert int(cnt.item()) > n_ln and float(g.float().abs().max()) == 65504.0
+        # GEGLU epilogue writing f16 rows: a huge bias on the value half saturates the product
+        n0 = int(cnt.item())
+        K, inner = 64, 64
+        w, b = rnd((2 * inner, K), dev, 91, 0.1), torch.zeros((2 * inner,), device=dev)
+        b[:inner] = 1.0e5; b[inner:] = 10.0
+        wp, bp = pack.pack_geglu_x2(w, b, "bf16x3m")
+        o = ops.linear(split_f16_act(rnd((128, K), dev, 92)), wp, bp, act=2, split_out="f16", tile_hint=25, split_k=1)
+        assert int(cnt.item()) > n0 and float(o.float().abs().max()) == 65504.0
+        ops.SAT_COUNTER = None
+        n1 = int(cnt.item())
+        ops.layernorm(x, gamma, beta, split_out="f16")
+        assert int(cnt.item()) == n1, "no counter, no counting"
+    finally:
+        ops.SAT_COUNTER = old
+
+
+def test_outlier_heavy_weights(dev):
+    """real checkpoints have weight outliers, and pack.split_f16 scales per TENSOR - the lo halves of small weights in
+    a tensor with a 1000x outlier are f16 subnormals. What that costs (pack.split_f16 docstring): hi + lo keeps an absolute error of
+    2^-38 |w|_max. Heavy-tailed weights (Student-t, 2 dof, + planted 1000x outliers) and activations with 50x outlier channels: the
+    operand still represents the weight to 2^-20 of each ROW's norm, and the GEMM matches fp64 math on the operands it multiplies."""
+    from geo4d_amd import ops, pack
+    M, K, N = 512, 1024, 256
+    g = torch.Generator(device="cpu").manual_seed(7)
+    t = torch.distributions.StudentT(2.0).sample((N, K)).clamp(-200, 200) * 0.02
+    t[::7, ::131] *= 1000.0
+    w = t.to(dev)
+    x = rnd((M, K), dev, 95)
+    x[:, ::97] *= 50.0
+    wp = pack.split_f16(w)
+    rep = weight_seen(wp)
+    row_err = (rep - w.double()).norm(dim=1) / w.double().norm(dim=1)
+    assert float(row_err.max()) < 2.0 ** -20, f"weight rows represented to {float(row_err.max()):.2e}"
+    # per weight: 2^-22 relative while lo is a normal f16, 2^-38 |w|_max absolute once it is subnormal (one factor 2 of slack on each)
+    amax = float(w.abs().max())
+    assert bool(((rep - w.double()).abs() <= w.double().abs() * 2.0 ** -21 + amax * 2.0 ** -37).all())
+    assert bool((w.abs() < amax * 2.0 ** -14).any()), "the test must contain weights whose lo half is subnormal"
+    out = ops.linear(split_f16_act(x), wp, None)
+    close("outlier GEMM vs fp64 on its operands", out, a_seen(x) @ rep.t())
+    full = x.double() @ w.double().t()
+    assert rel(out.double(), full) < 6e-4
 
 
 @pytest.mark.parametrize("fps", [1, 4])
@@ -131,8 +208,8 @@ def test_groupnorm_f16_split_output_and_fused_statistics(dev, fps):
     gamma, beta = rnd((C,), dev, 41) + 1.0, rnd((C,), dev, 42)
     plain = ops.groupnorm(x, gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True)
     sp = ops.groupnorm(x, gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True, split_out="f16")
-    assert isinstance(sp, ops.SplitAct) and sp.dtype == torch.float16 and sp.shape == (F * H * W, 2 * C)
-    assert torch.equal(sp.view(torch.int16), split_f16_act(plain).view(torch.int16)), "f16 split output differs from split(plain GroupNorm)"
+    assert not isinstance(sp, ops.SplitAct) and sp.dtype == torch.float16 and sp.shape == (F * H * W, C)
+    assert torch.equal(sp.view(torch.int16), split_f16_act(plain).view(torch.int16)), "f16 output differs from f16(plain GroupNorm)"
     wc, bc = rnd((C, C, 3, 3), dev, 43, 0.02), rnd((C,), dev, 44)
     wp = pack.pack_conv2d_x2(wc, "bf16x3m")
     old = ops.GN_FUSED_STATS
@@ -187,8 +264,8 @@ def test_layernorm_f16_split_output(dev, C):
     gamma, beta = rnd((C,), dev, 61) + 1.0, rnd((C,), dev, 62)
     plain = ops.layernorm(x, gamma, beta)
     sp = ops.layernorm(x, gamma, beta, split_out="f16")
-    assert isinstance(sp, ops.SplitAct) and sp.dtype == torch.float16 and sp.shape == (M, 2 * C)
-    assert torch.equal(sp.view(torch.int16), split_f16_act(plain).view(torch.int16)), "f16 split output differs from split(plain LayerNorm)"
+    assert not isinstance(sp, ops.SplitAct) and sp.dtype == torch.float16 and sp.shape == (M, C)
+    assert torch.equal(sp.view(torch.int16), split_f16_act(plain).view(torch.int16)), "f16 output differs from f16(plain LayerNorm)"
     b16 = ops.layernorm(x, gamma, beta, split_out=True)                       # the bf16 format is unchanged
     hi, lo = split_halves(b16)
     assert b16.dtype == torch.bfloat16 and rel(hi + lo, plain.double()) < 1e-5
@@ -211,9 +288,9 @@ def test_temporal_conv_two_pass(dev, tile):
 
 @pytest.mark.parametrize("tile", [0, 25, 27, 71, 74])
 def test_geglu_feed_forward_chain_two_pass(dev, tile):
-    """LayerNorm (f16 halves) -> two-pass GEGLU linear writing f16 halves (o_split = 2) -> two-pass ff-out with the residual: the chain
-    unet._ff runs in the bf16x3m mode, each stage against fp64 math on the operands it reads (the ff-out sees the HI half of what the
-    GEGLU epilogue stored). Tiles whose wave tiles cannot pair value / gate blocks must be refused."""
+    """LayerNorm (f16 rows) -> two-pass GEGLU linear writing f16 rows (o_split = 2) -> two-pass ff-out with the residual: the chain
+    unet._ff runs in the bf16x3m mode, each stage against fp64 math on the operands it reads (the ff-out sees the f16 the GEGLU
+    epilogue stored). Tiles whose wave tiles cannot pair value / gate blocks must be refused."""
     from geo4d_amd import ops, pack
     M, K, inner = 700, 256, 320
     x = rnd((M, K), dev, 80)
@@ -223,16 +300,15 @@ def test_geglu_feed_forward_chain_two_pass(dev, tile):
     wp2 = pack.pack_linear_x2(w2, "bf16x3m")
     xs = split_f16_act(x)
     g = both_grids(lambda: ops.linear(xs, wp, bp, act=2, split_out="f16", tile_hint=tile, split_k=1 if tile else 0))
-    assert isinstance(g, ops.SplitAct) and g.dtype == torch.float16 and g.shape == (M, 2 * inner)
+    assert not isinstance(g, ops.SplitAct) and g.dtype == torch.float16 and g.shape == (M, inner)
     perm = pack.geglu_perm(inner, dev)
     wu = torch.empty((2 * inner, K), device=dev, dtype=torch.float64)
     wu[perm] = weight_seen(wp)
     h = a_seen(x) @ wu.t() + b.double()
     ref = h[:, :inner] * TF.gelu(h[:, inner:])
-    hi, lo = split_halves(g)
-    close(f"geglu tile{tile}: hi + lo", hi + lo, ref)
-    # hi carries the value to f16 precision on its own (what the ff-out launch multiplies): the lo half is at most half an ulp of hi
-    assert bool((lo.abs() <= hi.abs() * 2.0 ** -10 + 2.0 ** -24).all()), "lo is larger than half an f16 ulp of hi"
+    hi = g.double()
+    # the stored f16 is the fp32 epilogue value rounded once: within half an f16 ulp of the fp64 reference (+ the fp32 accumulation error)
+    assert bool(((hi - ref).abs() <= ref.abs() * 2.0 ** -11 + 1e-5 * float(ref.abs().max()) + 2.0 ** -24).all()), "GEGLU f16 rows are further than half an ulp from fp64 math"
     y = both_grids(lambda: ops.linear(g, wp2, b2, residual=x, tile_hint=tile if tile != 27 else 25, split_k=1 if tile else 0))
     close(f"ff-out tile{tile}", y, hi @ weight_seen(wp2).t() + b2.double() + x.double())
     for bad in (23, 72, 73):

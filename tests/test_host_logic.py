@@ -128,7 +128,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.geo4d_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define GEO4D_ABI_VERSION (\d+)", hdr).group(1))
-    assert ctypes.sizeof(_lib.ConvGemm) == 9 * 8 + 9 * 8 + 27 * 4 + 4 + 3 * 4 + 4 + 8, ctypes.sizeof(_lib.ConvGemm)   # + o_split (+ pad), gn_colsum
+    assert ctypes.sizeof(_lib.ConvGemm) == 9 * 8 + 9 * 8 + 27 * 4 + 4 + 3 * 4 + 4 + 8 + 8, ctypes.sizeof(_lib.ConvGemm)   # + o_split (+ pad), gn_colsum, sat_count (ABI 8)
     assert lib.geo4d_groupnorm_workspace(16, 2560, 32, 1) == (16 * 64 * 32 * 3 + 16 * 32 * 2) * 4
     # argument validation happens on the host before any launch: bad descriptors return -EINVAL with a message
     p = _lib.ConvGemm()
@@ -373,8 +373,14 @@ def test_two_pass_f16_host_side_contracts():
     assert z._x2_alpha == 1.0 and float(z.abs().max()) == 0.0
     w = pack.split_f16(torch.randn((8, 32), generator=g))
     x32, a16 = torch.randn((4, 32), generator=g), ops.new_split(4, 32, "cpu", "f16")
-    assert ops.is_x2_weight(w) and not ops.is_x2_weight(w.clone()) and ops.kdim(w, a16) == 32 and ops.act_k(a16) == 32      # (the scale travels as an attribute of THE packed tensor)
-    assert a16.dtype == torch.float16 and ops.new_split(4, 32, "cpu").dtype == torch.bfloat16
+    assert ops.is_x2_weight(w) and ops.kdim(w, a16) == 32 and ops.act_k(a16) == 32
+    # round 6: the scale travels with the tensor through copies (X2Weight subclass) and is dropped - loudly, at the launch - by anything that changes the layout
+    for moved in (w.clone(), w.detach(), w.to(torch.float16), w.contiguous(), w.to("cpu")):
+        assert ops.is_x2_weight(moved) and moved._x2_alpha == w._x2_alpha and torch.equal(moved.as_subclass(torch.Tensor), w.as_subclass(torch.Tensor))
+    for broken in (w[:4], w.reshape(16, -1), w.float(), w + 0):
+        assert not ops.is_x2_weight(broken)
+    assert a16.dtype == torch.float16 and tuple(a16.shape) == (4, 32) and not isinstance(a16, ops.SplitAct)       # plain f16 rows: 2 bytes per element
+    assert ops.new_split(4, 32, "cpu").dtype == torch.bfloat16 and tuple(ops.new_split(4, 32, "cpu").shape) == (4, 64)
     assert ops.split_fmt(False) == (0, None) and ops.split_fmt(True) == (1, "bf16") and ops.split_fmt("f16") == (2, "f16")
     import pytest
     with pytest.raises(ValueError):

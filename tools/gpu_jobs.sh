@@ -9,7 +9,7 @@
 # is the all-in-one evidence job. A job that names build_b/ or gpurun_ab_r4/ needs that directory prepared in the container first.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 JOB=${1:?job name}; shift
-TAG=${TAG:-r5_$JOB}
+TAG=${TAG:-r6_$JOB}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -31,6 +31,24 @@ case $JOB in
     ;;
   attn)
     timeout 600 python tools/attn_bench.py "$@" > $O/attn.log 2>&1; show $O/attn.log
+    ;;
+  r6a)         # first call of round 6: plain f16 activation rows for the two-pass GEMMs (ABI 8) - correct? same smoke bits as round 5 (5.298e-4)? faster?
+    ( time timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_presplit_gpu.py tests/test_gemm_v3_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
+    ( time timeout 1200 python -m pytest tests/test_fullsize_gpu.py tests/test_parity_gpu.py -m gpu -q -x -s ) > $O/pytest_full.log 2>&1; echo "pytest rc=$?" >> $O/pytest_full.log
+    grep -E "^\[|passed|failed|rc=|Error|assert" $O/pytest_full.log | cut -c1-300 | tail -14
+    for i in 1 2; do
+      timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_$i.json 2> $O/bench_$i.err
+      python - <<PY
+import json
+try:
+    d = json.loads([l for l in open("$O/bench_$i.json") if l.startswith("{")][-1]); r = d["roofline"]
+    print("run $i:", round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "issued", round(r["frac_issued"], 3), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print("run $i failed", e)
+PY
+    done
     ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
