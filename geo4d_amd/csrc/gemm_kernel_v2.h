@@ -107,7 +107,7 @@ inline bool colsum_fast_ok(const geo4d_conv_gemm_t& p, int sp) {
 // The two-pass f16 type has no 256x256 instantiation (that tile spills a few registers around its K loop, and the long-K convolutions
 // the type exists for run on the phased tiles): hint 22 means the 160x320 tile there - same bits, every tile sums in the same order.
 // (GEGLU needs wave tiles a multiple of 64 columns wide, which 160x320 is not: 128x128 there.)
-template <typename T> inline int v2_effective_hint(int hint, int act = 0) { return (IsTwoPass<T>::value && hint == 22) ? (act == 2 ? 25 : 23) : hint; }
+template <typename T> inline int v2_effective_hint(int hint, int act = 0, int o_split = 0) { return (IsTwoPass<T>::value && hint == 22) ? ((act == 2 || o_split) ? 25 : 23) : hint; }
 inline int v2_wave_rows(int hint) { return hint == 22 ? 64 : hint == 23 ? 80 : hint == 25 ? 64 : (hint == 27 || hint == 28) ? 32 : 0; }
 __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes lr of a 16-lane row, fixed order (DPP: xor 1, xor 2, half mirror, mirror)
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
@@ -808,7 +808,7 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
 template <typename T>
 int launch_v2_typed(const geo4d_conv_gemm_t& p_in, hipStream_t stream) {
     geo4d_conv_gemm_t p = p_in;
-    p.tile_hint = v2_effective_hint<T>(p_in.tile_hint, p_in.act);
+    p.tile_hint = v2_effective_hint<T>(p_in.tile_hint, p_in.act, p_in.o_split);
     if constexpr (std::is_same<T, float>::value || std::is_same<T, f16_t>::value) {
         geo4d_set_error("conv_gemm: tile hints 22..28 serve bf16 / bf16x3 (the exact-f32 and the f16 modes stay on hints 0..17)");
         return GEO4D_EINVAL;

@@ -361,6 +361,10 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         if cfg is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
+        if p.o_split == 2:
+            # the f16-row epilogue lives on the tiles whose wave tiles are a multiple of 64 columns wide (25, 27, 71, 74): a tile borrowed from
+            # the bf16x3 entry of the same shape goes to its nearest such neighbour, and there is no split-K
+            tile_hint, split_k = {22: 25, 23: 25, 28: 27, 72: 71, 73: 74}.get(tile_hint, tile_hint), min(split_k, 1)
     if gn_stats and GN_FUSED_STATS and not p.o_split and batch == 1 and out.dim() == 2 and out.shape[0] == M:
         # the consumer GroupNorm's statistics pass, for free: per row block and column (sum, sum of squares) from the epilogue. The library
         # says how many rows one entry of THIS launch covers (32 for the first generation, the wave tile's rows for the second / third; 0 =
@@ -606,7 +610,7 @@ def _launch_attention(lib, p):
         e0.record()
         _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
         e1.record()
-        ATTN_TIMELINE.append((4.0 * p.B * p.H * p.Nq * p.Nk[0] * 64, e0, e1))
+        ATTN_TIMELINE.append((4.0 * p.B * p.H * p.Nq * p.Nk[0] * 64, e0, e1, 3 if p.dtype == BF16X3 else 1))     # (flops, events, MFMAs issued per product)
         return
     _lib.check(lib.geo4d_attention(C.byref(p), _stream()), "geo4d_attention")
 

@@ -278,17 +278,27 @@ class UNetModel(ParamTree):
         lin_ln = pack.pack_linear_x2 if x2("ln") else pack.pack_linear
 
         def block(p, cross):
-            b = {"x2ln": x2("ln"), "x2ff": x2("ff")}
+            # class "attn" (round 6): the spatial SELF-attention chain in f16 - LayerNorm writes f16 rows, q | k leave a two-pass GEMM as f16
+            # rows, V^T a one-pass f16 GEMM (the weight rounded to f16 too: it is the MFMA's A side there), the attention kernel is the
+            # single-pass f16 one, its f16 output feeds a two-pass to_out (tests/precision_sim.py "self-attention CHAIN")
+            b = {"x2ln": x2("ln"), "x2ff": x2("ff"), "x2attn": bool(cross and x2("attn"))}
             for a in ("attn1", "attn2"):
+                x2o = False
                 if a == "attn2" and cross:
                     b[a + ".q"] = lin_ln(sd[f"{p}.{a}.to_q.weight"], dt)            # LayerNorm -> q (plain rows): class "ln"
                 elif cross:      # spatial self-attention: q|k fused, V projected transposed (flash kernel wants V^T)
-                    b[a + ".qk"] = pack.pack_linear(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"]], 0), dt)
-                    b[a + ".v"] = pack.pack_linear(sd[f"{p}.{a}.to_v.weight"], dt)
+                    wqk = torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"]], 0)
+                    if b["x2attn"]:
+                        b[a + ".qk"] = pack.pack_linear_x2(wqk, dt)
+                        b[a + ".v"] = pack.pack_linear(sd[f"{p}.{a}.to_v.weight"], "f16")
+                        x2o = True
+                    else:
+                        b[a + ".qk"] = pack.pack_linear(wqk, dt)
+                        b[a + ".v"] = pack.pack_linear(sd[f"{p}.{a}.to_v.weight"], dt)
                 else:            # temporal attention: LayerNorm -> q | k | v (plain rows): class "ln"
                     b[a + ".qkv"] = lin_ln(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"],
                                                       sd[f"{p}.{a}.to_v.weight"]], 0), dt)
-                b[a + ".o"] = (pack.pack_linear(sd[f"{p}.{a}.to_out.0.weight"], dt), f32(f"{p}.{a}.to_out.0.bias"))
+                b[a + ".o"] = ((pack.pack_linear_x2 if x2o else pack.pack_linear)(sd[f"{p}.{a}.to_out.0.weight"], dt), f32(f"{p}.{a}.to_out.0.bias"))
             if x2("ff"):
                 b["ff1"] = pack.pack_geglu_x2(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], dt)
                 b["ff2"] = (pack.pack_linear_x2(sd[p + ".ff.net.2.weight"], dt), f32(p + ".ff.net.2.bias"))
@@ -444,9 +454,16 @@ class UNetModel(ParamTree):
         blk = e["blk"]
         sp = self.presplit
         x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=N, eps=1e-6, split_out="f16" if e.get("x2in") else sp), *e["in"])
-        n1 = ops.layernorm(x, *blk["norm1"], split_out=sp)
         x3 = self.compute_dtype.x3
-        if sp and N % 8 == 0:
+        if blk.get("x2attn"):
+            # bf16x3m class "attn": the whole self-attention branch in f16 (one MFMA per product inside the attention kernel, two in the
+            # projections around it); everything it touches is a normalised branch activation, the residual stream `x` stays f32
+            n1 = ops.layernorm(x, *blk["norm1"], split_out="f16")
+            qk = ops.linear(n1, blk["attn1.qk"], split_out="f16")                         # f16 rows [M, 2C]
+            vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)                    # f16 V^T per frame: [F, C, Npad]
+            att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125)
+        elif sp and N % 8 == 0:
+            n1 = ops.layernorm(x, *blk["norm1"], split_out=sp)
             # bf16x3: q | k and V^T leave their projections in the pre-split operand format (o_split epilogue), so the attention kernel
             # does not split K / V^T fragments per tile and wave (round 4: -30 % of its VALU instructions). 2 bf16 per element:
             qk = ops.linear(n1, blk["attn1.qk"], split_out=True)                          # SplitAct [M, 2 * 2C]
@@ -454,6 +471,7 @@ class UNetModel(ParamTree):
             att = ops.attention(qk[:, :2 * C_], [(qk[:, 2 * C_:], vt.reshape(-1, 2 * npad), N, 1, C_ * 2 * npad)], B=F_, H=heads, Nq=N,
                                 scale=0.125, x3=True, split_out=sp, qkv_split=True)
         else:
+            n1 = ops.layernorm(x, *blk["norm1"], split_out=sp)
             qk = ops.linear(n1, blk["attn1.qk"])
             vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
             att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)

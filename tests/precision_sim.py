@@ -26,7 +26,7 @@ DT = {"f32": None, "f16": torch.float16, "bf16": torch.bfloat16, "bf16x2": "bf16
 
 
 class Scheme:
-    def __init__(self, w="f32", a="f32", s="f32", p=None, h1=None, name=None, c3a=None, c3w=None, vae3=False, two_pass=()):
+    def __init__(self, w="f32", a="f32", s="f32", p=None, h1=None, name=None, c3a=None, c3w=None, vae3=False, two_pass=(), attn1=None):
         """`c3a` / `c3w` (round 5, the mixed-pass question of VERDICT r4 #8): storage of the A operand / the weights of the long-K 3x3
         convolutions ONLY (ResBlock in / out convs, down / up samplers; with `vae3` also the VAE's 3x3 convs); None = as `a` / `w`."""
         self.w, self.a, self.s, self.p, self.h1 = DT[w], DT[a], DT[s], DT[p if p else a], DT[h1 if h1 else a]
@@ -34,6 +34,9 @@ class Scheme:
         # classes of GEMMs (beyond the 3x3 convs) whose A operand is additionally rounded to f16 (weights stay ~exact: f16 hi + lo):
         # "tconv" temporal 3-tap convs, "ff" GEGLU feed-forward (both linears), "proj" q / k / v / out / proj_in / proj_out linears
         self.two_pass = frozenset(two_pass)
+        # round 6: operands of the SPATIAL SELF-attention's two GEMMs (attention.hip): None = as `a` / `p`; "x2" = q and P one f16, K and V f16 hi +
+        # lo (two f16 MFMAs per product); "f16" = q, K, V, P one f16 each (one MFMA per product)
+        self.attn1 = attn1
         self.name = name or f"w={w} a={a} s={s} p={p or a} h1={h1 or a}" + (f" c3a={c3a} c3w={c3w}" if (c3a or c3w) else "")
 
     @staticmethod
@@ -74,6 +77,8 @@ class S_:
         if cls is not None and any(c in self.sc.two_pass for c in ((cls,) if isinstance(cls, str) else cls)):
             x = x.to(torch.float16).float()
         w = self.w(p + ".weight")
+        if cls is not None and "v1" in cls and "wv16" in self.sc.two_pass:      # round 6: the V^T projection as ONE f16 pass (weight rounded to f16 too)
+            w = self.sd[p + ".weight"].to(torch.float16).float()
         return F.linear(x, w.reshape(w.shape[0], -1), self.sd.get(p + ".bias") if bias else None)
 
     def gn(self, x, p, eps):
@@ -98,15 +103,21 @@ class S_:
         return F.conv3d(x, self.w(p + ".weight"), self.sd[p + ".bias"], padding=(1, 0, 0))
 
 
-def _mha(sc, q, k, v, heads):
+def _mha(sc, q, k, v, heads, self1=False):
     b, n, _ = q.shape
     d = q.shape[-1] // heads
     split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3)
+    mode = sc.attn1 if self1 else None
+    h16 = lambda t: t.to(torch.float16).float()
+    if mode == "x2":
+        q, k, v = h16(q), Scheme._q(k, "f16x2"), Scheme._q(v, "f16x2")
+    elif mode == "f16":
+        q, k, v = h16(q), h16(k), h16(v)
     s = split(q) @ split(k).transpose(-1, -2) * d ** -0.5
     m = s.amax(-1, keepdim=True)
     pr = torch.exp(s - m)
     l = pr.sum(-1, keepdim=True)                        # the engine sums the UNROUNDED fp32 p
-    o = (sc.qp(pr) @ split(v)) / l
+    o = ((h16(pr) if mode else sc.qp(pr)) @ split(v)) / l
     return o.permute(0, 2, 1, 3).reshape(b, n, heads * d)
 
 
@@ -118,7 +129,7 @@ def _attention(S, x, p, heads, context=None, image_cross=False):
     q = sc.qa(S.lin(x, p + ".to_q", False, cls=("proj", "ln" if (context is not None or tself) else "qk1")))
     if context is None:
         out = _mha(sc, q, sc.qa(S.lin(x, p + ".to_k", False, cls=("proj", "ln" if tself else "qk1"))),
-                   sc.qa(S.lin(x, p + ".to_v", False, cls=("proj", "ln" if tself else "v1"))), heads)
+                   sc.qa(S.lin(x, p + ".to_v", False, cls=("proj", "ln" if tself else "v1"))), heads, self1=not tself)
     else:
         text, img = sc.qa(context[:, :77]), sc.qa(context[:, 77:])
         out = _mha(sc, q, sc.qa(S.lin(text, p + ".to_k", False)), sc.qa(S.lin(text, p + ".to_v", False)), heads)
@@ -319,11 +330,22 @@ SCHEMES = [
     Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", name="two-pass f16 on the U-Net's 3x3 convs"),
     Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff"), name="bf16x3m mode: two-pass f16 on conv3x3 + vae3x3 + tconv + ln + ff"),
     Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff", "proj_in", "proj_out", "raw"), name="... + the stream-rounding classes (proj_in / proj_out / raw): rejected"),
+    # round 6: the spatial self-attention's own GEMMs (S = q.K^T, O = P.V), alone and on top of the bf16x3m classes
+    Scheme("bf16x2", "bf16x2", "f32", attn1="x2", name="bf16x3 + self-attention two-pass (q, P one f16; K, V f16 hi + lo)"),
+    Scheme("bf16x2", "bf16x2", "f32", attn1="f16", name="bf16x3 + self-attention ONE pass (q, K, V, P one f16)"),
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff"), attn1="x2", name="bf16x3m + self-attention two-pass"),
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff"), attn1="f16", name="bf16x3m + self-attention ONE pass"),
+    Scheme("bf16x2", "bf16x2", "f32", two_pass=("qk1", "v1", "attn_out"), attn1="f16", name="bf16x3 + self-attention CHAIN (n1 f16 -> two-pass q|k, V; one-pass attention; two-pass to_out)"),
+    Scheme("bf16x2", "bf16x2", "f32", two_pass=("qk1", "v1", "attn_out", "wv16"), attn1="f16", name="bf16x3 + self-attention CHAIN, V^T projection in ONE f16 pass (W_v rounded to f16)"),
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff", "qk1", "v1", "attn_out"), attn1="f16", name="bf16x3m + self-attention CHAIN"),
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff", "qk1", "v1", "attn_out", "wv16"), attn1="f16", name="bf16x3m + self-attention CHAIN, V^T in ONE f16 pass"),
 ]
+if os.environ.get("SIM_ONLY"):
+    SCHEMES = [sc for sc in SCHEMES if any(k in sc.name for k in os.environ["SIM_ONLY"].split(","))]
 
 
 def main():
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(int(os.environ.get("SIM_THREADS", os.cpu_count() or 1)))
     G = os.path.join(ROOT, "tests", "golden")
     u = torch.load(os.path.join(G, "unet_tiny.pt"), weights_only=False)
     v = torch.load(os.path.join(G, "vae_tiny.pt"), weights_only=False)

@@ -10,7 +10,9 @@ from oracle.params import seeded_state_dict
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MODES = [("f32", 2e-4), ("bf16x3", 2e-4), ("f16", 1e-2), ("bf16", 5e-2)]
+# bf16x3m (round 6): the front-end has no two-pass class (precision.TWO_PASS_CLASSES live in the U-Net and the VAE decoder), so the headline mode
+# runs bf16x3 arithmetic here and is held to bf16x3's tolerance
+MODES = [("f32", 2e-4), ("bf16x3", 2e-4), ("bf16x3m", 2e-4), ("f16", 1e-2), ("bf16", 5e-2)]
 
 
 def rel(a, b):

@@ -50,6 +50,27 @@ except Exception as e:
 PY
     done
     ;;
+  r6b)         # class "attn" (f16 self-attention chain) + bf16x3m in every MODES list: parity everywhere? same-box three-way: round-5 tree / plain f16 rows / + attn
+    ( time timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_host_logic.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -8
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
+    ( time timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_frontend_gpu.py tests/test_sizes_gpu.py tests/test_fullsize_gpu.py -m gpu -q -s -k "not 50_step_window" ) > $O/pytest_full.log 2>&1; echo "pytest rc=$?" >> $O/pytest_full.log
+    grep -E "bf16x3m|passed|failed|rc=|Error|^FAILED" $O/pytest_full.log | cut -c1-420 | tail -40
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "issued", round(r["frac_issued"], 3), "attn", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.get("attention", {}).items()}, "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for i in 1 2; do
+      ( cd gpurun_ab_r5 && timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_r5_$i.json 2> $O/bench_r5_$i.err ); bl $O/bench_r5_$i.json "r5 tree run $i:"
+      GEO4D_TWO_PASS=conv3x3,vae3x3,tconv,ln,ff timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_noattn_$i.json 2> $O/bench_noattn_$i.err; bl $O/bench_noattn_$i.json "r6 f16 rows, no attn class run $i:"
+      timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_attn_$i.json 2> $O/bench_attn_$i.err; bl $O/bench_attn_$i.json "r6 + attn class run $i:"
+    done
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
