@@ -140,6 +140,9 @@ def _ld(t):
 
 _WS = {}
 WORKSPACE_BYTES = 256 << 20
+# (Round 6 built split-K WITHOUT the reduce launch - wave tickets, the last arrival of a (tile, wave) position sums the slabs and runs the
+# epilogue, bit-equal to the reduce kernel - and measured it slower twice: with agent-scope release / acquire fences 6.37 -> 5.57 frames/s,
+# with sc1 write-through slabs and no fence 6.31 -> 6.08. Removed; profiles/r06_splitk_fused.md.)
 
 # ---- per-shape launch tuning ------------------------------------------------------------------------------------
 # geo4d_conv_gemm has three kernel generations x tile shapes x split-K factors (include/geo4d_hip.h tile_hint); the C-side heuristic is a fallback. The host keeps a table

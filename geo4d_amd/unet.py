@@ -281,7 +281,10 @@ class UNetModel(ParamTree):
             # class "attn" (round 6): the spatial SELF-attention chain in f16 - LayerNorm writes f16 rows, q | k leave a two-pass GEMM as f16
             # rows, V^T a one-pass f16 GEMM (the weight rounded to f16 too: it is the MFMA's A side there), the attention kernel is the
             # single-pass f16 one, its f16 output feeds a two-pass to_out (tests/precision_sim.py "self-attention CHAIN")
-            b = {"x2ln": x2("ln"), "x2ff": x2("ff"), "x2attn": bool(cross and x2("attn"))}
+            # class "tattn" (round 6): the TEMPORAL attention branch on f16 rows - its two-pass q | k | v projection (class "ln") writes f16 rows,
+            # temporal_attn_kernel's f16 instantiation reads half the bytes (the kernel is HBM-bound; its arithmetic is fp32 VALU either way) and
+            # writes f16 rows, which feed a two-pass to_out
+            b = {"x2ln": x2("ln"), "x2ff": x2("ff"), "x2attn": bool(cross and x2("attn")), "x2tattn": bool(not cross and x2("tattn") and x2("ln"))}
             for a in ("attn1", "attn2"):
                 x2o = False
                 if a == "attn2" and cross:
@@ -298,6 +301,7 @@ class UNetModel(ParamTree):
                 else:            # temporal attention: LayerNorm -> q | k | v (plain rows): class "ln"
                     b[a + ".qkv"] = lin_ln(torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"],
                                                       sd[f"{p}.{a}.to_v.weight"]], 0), dt)
+                    x2o = b["x2tattn"]
                 b[a + ".o"] = ((pack.pack_linear_x2 if x2o else pack.pack_linear)(sd[f"{p}.{a}.to_out.0.weight"], dt), f32(f"{p}.{a}.to_out.0.bias"))
             if x2("ff"):
                 b["ff1"] = pack.pack_geglu_x2(sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"], dt)
@@ -492,9 +496,10 @@ class UNetModel(ParamTree):
         blk = e["blk"]
         sp = self.presplit
         x = ops.linear(ops.groupnorm(h, *e["norm"], F=F_, HW=HW, eps=1e-6, frames_per_stat=T, split_out="f16" if e.get("x2in") else sp), *e["in"])
+        t16 = blk.get("x2tattn")
         for a, n in (("attn1", "norm1"), ("attn2", "norm2")):
-            qkv = ops.linear(ops.layernorm(x, *blk[n], split_out="f16" if blk.get("x2ln") else sp), blk[a + ".qkv"])
-            att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125, split_out=sp)
+            qkv = ops.linear(ops.layernorm(x, *blk[n], split_out="f16" if blk.get("x2ln") else sp), blk[a + ".qkv"], split_out="f16" if t16 else False)
+            att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125, split_out=False if t16 else sp)
             x = ops.linear(att, *blk[a + ".o"], residual=x)
         x = self._ff(blk, x)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)

@@ -37,6 +37,7 @@ class Scheme:
         # round 6: operands of the SPATIAL SELF-attention's two GEMMs (attention.hip): None = as `a` / `p`; "x2" = q and P one f16, K and V f16 hi +
         # lo (two f16 MFMAs per product); "f16" = q, K, V, P one f16 each (one MFMA per product)
         self.attn1 = attn1
+        self.attnT = None       # "f16": the TEMPORAL attention's q / k / v arrive as f16 rows (its arithmetic stays fp32 VALU)
         self.name = name or f"w={w} a={a} s={s} p={p or a} h1={h1 or a}" + (f" c3a={c3a} c3w={c3w}" if (c3a or c3w) else "")
 
     @staticmethod
@@ -103,12 +104,14 @@ class S_:
         return F.conv3d(x, self.w(p + ".weight"), self.sd[p + ".bias"], padding=(1, 0, 0))
 
 
-def _mha(sc, q, k, v, heads, self1=False):
+def _mha(sc, q, k, v, heads, self1=False, tself_f16=False, cross=False):
     b, n, _ = q.shape
     d = q.shape[-1] // heads
     split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3)
-    mode = sc.attn1 if self1 else None
+    mode = sc.attn1 if self1 else (getattr(sc, "attnC", None) if cross else None)
     h16 = lambda t: t.to(torch.float16).float()
+    if tself_f16:
+        q, k, v = h16(q), h16(k), h16(v)
     if mode == "x2":
         q, k, v = h16(q), Scheme._q(k, "f16x2"), Scheme._q(v, "f16x2")
     elif mode == "f16":
@@ -129,13 +132,13 @@ def _attention(S, x, p, heads, context=None, image_cross=False):
     q = sc.qa(S.lin(x, p + ".to_q", False, cls=("proj", "ln" if (context is not None or tself) else "qk1")))
     if context is None:
         out = _mha(sc, q, sc.qa(S.lin(x, p + ".to_k", False, cls=("proj", "ln" if tself else "qk1"))),
-                   sc.qa(S.lin(x, p + ".to_v", False, cls=("proj", "ln" if tself else "v1"))), heads, self1=not tself)
+                   sc.qa(S.lin(x, p + ".to_v", False, cls=("proj", "ln" if tself else "v1"))), heads, self1=not tself, tself_f16=bool(tself and sc.attnT == "f16"))
     else:
         text, img = sc.qa(context[:, :77]), sc.qa(context[:, 77:])
-        out = _mha(sc, q, sc.qa(S.lin(text, p + ".to_k", False)), sc.qa(S.lin(text, p + ".to_v", False)), heads)
+        out = _mha(sc, q, sc.qa(S.lin(text, p + ".to_k", False)), sc.qa(S.lin(text, p + ".to_v", False)), heads, cross=True)
         if image_cross:
-            out = out + _mha(sc, q, sc.qa(S.lin(img, p + ".to_k_ip", False)), sc.qa(S.lin(img, p + ".to_v_ip", False)), heads)
-    return S.lin(sc.qa(out), p + ".to_out.0", cls=("proj", "attn_out"))
+            out = out + _mha(sc, q, sc.qa(S.lin(img, p + ".to_k_ip", False)), sc.qa(S.lin(img, p + ".to_v_ip", False)), heads, cross=True)
+    return S.lin(sc.qa(out), p + ".to_out.0", cls=("proj", "attn_out", "attn_out_t" if tself else "attn_out_c" if context is not None else "attn_out_s"))
 
 
 def _block(S, x, p, heads, context, image_cross):
@@ -339,6 +342,20 @@ SCHEMES = [
     Scheme("bf16x2", "bf16x2", "f32", two_pass=("qk1", "v1", "attn_out", "wv16"), attn1="f16", name="bf16x3 + self-attention CHAIN, V^T projection in ONE f16 pass (W_v rounded to f16)"),
     Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff", "qk1", "v1", "attn_out"), attn1="f16", name="bf16x3m + self-attention CHAIN"),
     Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=("tconv", "ln", "ff", "qk1", "v1", "attn_out", "wv16"), attn1="f16", name="bf16x3m + self-attention CHAIN, V^T in ONE f16 pass"),
+]
+def _with(sc, **kw):
+    for k, v in kw.items():
+        setattr(sc, k, v)
+    return sc
+
+
+M6 = ("tconv", "ln", "ff", "qk1", "v1", "attn_out_s", "wv16")      # the round-6 default: bf16x3m classes + the spatial self-attention chain ("attn")
+SCHEMES += [
+    Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6, attn1="f16", name="R6 default: bf16x3m + attn (to_out of the SPATIAL self-attention only)"),
+    _with(Scheme("bf16x2", "bf16x2", "f32", two_pass=("ln", "attn_out_t"), name="R6 bf16x3 + temporal attention chain alone (q | k | v f16 rows, two-pass to_out)"), attnT="f16"),
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6 + ("attn_out_t",), attn1="f16", name="R6 default + temporal attention chain (tattn)"), attnT="f16"),
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6 + ("attn_out_c",), attn1="f16", name="R6 default + cross-attention chain (q, K, V, P one f16; two-pass to_out) (cattn)"), attnC="f16"),
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6 + ("attn_out_c", "attn_out_t"), attn1="f16", name="R6 default + tattn + cattn"), attnC="f16", attnT="f16"),
 ]
 if os.environ.get("SIM_ONLY"):
     SCHEMES = [sc for sc in SCHEMES if any(k in sc.name for k in os.environ["SIM_ONLY"].split(","))]

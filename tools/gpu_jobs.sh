@@ -71,6 +71,47 @@ PY
       timeout 400 python bench.py --steps 3 --warmup 1 --dtype bf16x3m --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_attn_$i.json 2> $O/bench_attn_$i.err; bl $O/bench_attn_$i.json "r6 + attn class run $i:"
     done
     ;;
+  r6c)         # split-K without a reduce launch (wave tickets): bit-equal to the reduce kernel? faster? (same-box A/B by environment switch)
+    ( time timeout 1200 python -m pytest tests/test_splitk_fused_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_f16x2_gpu.py tests/test_bf16x3_gpu.py tests/test_presplit_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_gemm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gemm.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_gemm.log | tail -8
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "frac", round(r["frac"], 4), "issued", round(r["frac_issued"], 3), "attn ms", round(r["attention"]["ms_per_unet_forward"], 3), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for i in 1 2; do
+      GEO4D_SPLITK_FUSED=0 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_reduce_$i.json 2> $O/bench_reduce_$i.err; bl $O/bench_reduce_$i.json "reduce kernel run $i:"
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_fused_$i.json 2> $O/bench_fused_$i.err; bl $O/bench_fused_$i.json "fused split-K run $i:"
+    done
+    cd /tmp
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-shipped-setting --no-clip-leg > $O/kt.log 2>&1
+    find /tmp/prof/kt -name "*kernel_stats.csv" -exec cp {} $O/kt_kernel_stats.csv \;
+    KT=$(find /tmp/prof/kt -name "*kernel_trace.csv" | head -1)
+    [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 40 > $O/phases.md 2>&1
+    head -60 $O/phases.md | cut -c1-200
+    ;;
+  r6d)         # split-K last arrival with sc1 write-through slabs instead of fences: correct (incl. 10x repeat at full chip)? A/B
+    ( time timeout 600 python -m pytest tests/test_splitk_fused_gpu.py -m gpu -q -x ) > $O/pytest_splitk.log 2>&1; echo "pytest rc=$?" >> $O/pytest_splitk.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_splitk.log | tail -8
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "frac", round(r["frac"], 4), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for i in 1 2; do
+      GEO4D_SPLITK_FUSED=0 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_reduce_$i.json 2> $O/bench_reduce_$i.err; bl $O/bench_reduce_$i.json "reduce kernel run $i:"
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_fused_$i.json 2> $O/bench_fused_$i.err; bl $O/bench_fused_$i.json "fused split-K run $i:"
+    done
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
