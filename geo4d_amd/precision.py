@@ -38,13 +38,16 @@ import torch
 # table of profiles/r05_two_pass_f16.md): conv3x3 = U-Net ResBlock convolutions, vae3x3 = VAE decoder ResnetBlock convolutions,
 # tconv = temporal 3-tap convolutions, proj_in = the transformers' GroupNorm -> proj_in linears, ln = the LayerNorm-fed projections that
 # write plain rows (cross-attention q, temporal q | k | v), ff = the GEGLU feed-forward (both linears), attn (round 6) = the spatial
-# self-attention branch: LayerNorm -> f16 rows -> two-pass q | k + one-pass f16 V^T -> the single-pass f16 attention kernel -> two-pass to_out.
+# self-attention branch: LayerNorm -> f16 rows -> two-pass q | k + one-pass f16 V^T -> the single-pass f16 attention kernel -> two-pass to_out;
+# cattn = the spatial cross-attention on f16 rows (f16 q, f16 copies of the cached context K / V^T, single-pass f16 dual-KV kernel, two-pass
+# to_out); tattn = the temporal attention on f16 rows (its q | k | v projection writes f16 rows, the HBM-bound kernel reads half the bytes,
+# two-pass to_out). Error / frames/s per class: profiles/r06_attention_chains_ab.md.
 # Default = classes whose A operand is a NORMALISED branch activation (GroupNorm / LayerNorm / GEGLU outputs) AND that pay for their
 # error (profiles/r05_two_pass_f16.md: frames/s and point-map error per class). proj_in is off by default: 3.7e-4 on the simulated smoke
 # window (tests/precision_sim.py) for 0.2 % of the step. Built, measured and REMOVED in round 5: the classes that round a RESIDUAL STREAM
 # to f16 (proj_out; the raw-activation launches: down / up samplers, skip connections, VAE upsamplers) - at BASELINE size they took the
 # 50-step point-map drift from 1.1e-4 to 5.3e-4 (the tiny smoke window to 9.98e-4) for +1 % frames/s.
-TWO_PASS_CLASSES = frozenset(c.strip() for c in os.environ.get("GEO4D_TWO_PASS", "conv3x3,vae3x3,tconv,ln,ff,attn").split(",") if c.strip())
+TWO_PASS_CLASSES = frozenset(c.strip() for c in os.environ.get("GEO4D_TWO_PASS", "conv3x3,vae3x3,tconv,ln,ff,attn,cattn,tattn").split(",") if c.strip())
 
 
 class Precision:

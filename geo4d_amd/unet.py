@@ -284,11 +284,15 @@ class UNetModel(ParamTree):
             # class "tattn" (round 6): the TEMPORAL attention branch on f16 rows - its two-pass q | k | v projection (class "ln") writes f16 rows,
             # temporal_attn_kernel's f16 instantiation reads half the bytes (the kernel is HBM-bound; its arithmetic is fp32 VALU either way) and
             # writes f16 rows, which feed a two-pass to_out
-            b = {"x2ln": x2("ln"), "x2ff": x2("ff"), "x2attn": bool(cross and x2("attn")), "x2tattn": bool(not cross and x2("tattn") and x2("ln"))}
+            # class "cattn" (round 6): the spatial CROSS-attention on f16 rows - q leaves its two-pass projection (class "ln") as f16 rows, the cached
+            # context K / V^T are kept as f16 copies, the dual-KV attention kernel runs its single-pass f16 instantiation, to_out is two-pass
+            b = {"x2ln": x2("ln"), "x2ff": x2("ff"), "x2attn": bool(cross and x2("attn")), "x2tattn": bool(not cross and x2("tattn") and x2("ln")),
+                 "x2cattn": bool(cross and x2("cattn") and x2("ln"))}
             for a in ("attn1", "attn2"):
                 x2o = False
                 if a == "attn2" and cross:
                     b[a + ".q"] = lin_ln(sd[f"{p}.{a}.to_q.weight"], dt)            # LayerNorm -> q (plain rows): class "ln"
+                    x2o = b["x2cattn"]
                 elif cross:      # spatial self-attention: q|k fused, V projected transposed (flash kernel wants V^T)
                     wqk = torch.cat([sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"]], 0)
                     if b["x2attn"]:
@@ -395,7 +399,7 @@ class UNetModel(ParamTree):
             k_t = k_i = None
             vt_t, vt_i = {}, {}
         else:
-            k_t, k_i, vt_t, vt_i, _ = hit["kv"]
+            k_t, k_i, vt_t, vt_i = hit["kv"][:4]
         k_t = ops.linear(text, P["k_text"], out=k_t)                          # every layer's text keys: [B*77, sum C]
         k_i = ops.linear(img, P["k_img"], out=k_i) if P["k_img"] is not None else None
         for L in self.all_layers():                                            # values, transposed per layer (V^T rows = channels)
@@ -409,7 +413,23 @@ class UNetModel(ParamTree):
                 ops.linear_t(e["wv_text"], text[b * 77:(b + 1) * 77], out=v[b])
             if k_i is not None:
                 vt_i[L.prefix] = ops.linear_t(e["wv_img"], img, out=vt_i.get(L.prefix))   # [C, B*T*16], frame f at columns 16f..
-        kv = (k_t, k_i, vt_t, vt_i, context)   # keeps `context` alive so its data_ptr stays unique
+        # f16 copies for the "cattn" class (refreshed in place like the f32 ones: a captured graph keeps valid pointers)
+        h16 = hit["kv"][5] if hit is not None else {}
+        if self.compute_dtype.two_pass("cattn") and self.compute_dtype.two_pass("ln") and self.presplit:
+            def half(name, t):
+                if t is None:
+                    return None
+                c = h16.get(name)
+                if c is None:
+                    c = h16[name] = torch.empty(t.shape, device=t.device, dtype=torch.float16)
+                c.copy_(t)
+                return c
+            half("k_t", k_t); half("k_i", k_i)
+            for pfx, v in vt_t.items():
+                half("vt_t." + pfx, v)
+            for pfx, v in vt_i.items():
+                half("vt_i." + pfx, v)
+        kv = (k_t, k_i, vt_t, vt_i, context, h16)   # keeps `context` alive so its data_ptr stays unique
         if hit is None:
             if len(self._ctx_cache) >= 8:
                 self._ctx_cache.pop(next(iter(self._ctx_cache)))
@@ -480,13 +500,20 @@ class UNetModel(ParamTree):
             vt, npad = ops.linear_t_batched(blk["attn1.v"], n1, F_, N)             # V^T per frame: [F, C, Npad]
             att = ops.attention(qk[:, :C_], [(qk[:, C_:], vt.reshape(-1, npad), N, 1, C_ * npad)], B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn1.o"], residual=x)
-        q = ops.linear(ops.layernorm(x, *blk["norm2"], split_out="f16" if blk.get("x2ln") else sp), blk["attn2.q"])
-        k_t, k_i, vt_t, vt_i, _ = kv
+        c16 = blk.get("x2cattn")
+        q = ops.linear(ops.layernorm(x, *blk["norm2"], split_out="f16" if blk.get("x2ln") else sp), blk["attn2.q"], split_out="f16" if c16 else False)
+        k_t, k_i, vt_t, vt_i, _, h16 = kv
         off, _ = e["kv"]
-        sets = [(k_t[:, off:off + C_], vt_t[L.prefix].reshape(-1, 80), 77, T, C_ * 80)]
-        if k_i is not None:
-            sets.append((k_i[:, off:off + C_], vt_i[L.prefix], 16, 1, 16))
-        att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
+        if c16:
+            sets = [(h16["k_t"][:, off:off + C_], h16["vt_t." + L.prefix].reshape(-1, 80), 77, T, C_ * 80)]
+            if k_i is not None:
+                sets.append((h16["k_i"][:, off:off + C_], h16["vt_i." + L.prefix], 16, 1, 16))
+            att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125)
+        else:
+            sets = [(k_t[:, off:off + C_], vt_t[L.prefix].reshape(-1, 80), 77, T, C_ * 80)]
+            if k_i is not None:
+                sets.append((k_i[:, off:off + C_], vt_i[L.prefix], 16, 1, 16))
+            att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
         x = self._ff(blk, x)
         return ops.linear(x, *e["out"], residual=h, gn_stats=True)

@@ -112,6 +112,28 @@ PY
       timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_fused_$i.json 2> $O/bench_fused_$i.err; bl $O/bench_fused_$i.json "fused split-K run $i:"
     done
     ;;
+  r6e)         # classes cattn / tattn (cross- and temporal-attention chains on f16 rows): parity + frames/s per class, same box; the 50-step reference fixture
+    BASE=conv3x3,vae3x3,tconv,ln,ff,attn
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "frac", round(r["frac"], 4), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for cls in $BASE $BASE,cattn $BASE,tattn $BASE,cattn,tattn; do
+      GEO4D_TWO_PASS=$cls timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$cls.log 2>&1; echo "$cls: $(grep 'bf16x3m' $O/smoke_$cls.log)"
+    done
+    for i in 1 2; do
+      for cls in $BASE $BASE,cattn $BASE,tattn $BASE,cattn,tattn; do
+        GEO4D_TWO_PASS=$cls timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_${cls}_$i.json 2> $O/bench_${cls}_$i.err; bl $O/bench_${cls}_$i.json "$cls run $i:"
+      done
+    done
+    ( time GEO4D_TWO_PASS=$BASE,cattn,tattn timeout 1500 python -m pytest tests/test_fullsize_gpu.py tests/test_parity_gpu.py -m gpu -q -s -k "full_size or window_end_to_end or ddim_sampler" ) > $O/pytest_full.log 2>&1; echo "pytest rc=$?" >> $O/pytest_full.log
+    grep -E "bf16x3m|passed|failed|rc=|Error|^FAILED" $O/pytest_full.log | cut -c1-520 | tail -20
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
