@@ -41,6 +41,23 @@ __global__ __launch_bounds__(256) void concat_channels_kernel(const u32x4* __res
     }
 }
 
+// f32 rows -> f16 rows (8 elements per lane: two 16-byte loads, one 16-byte store), clamped to the finite f16 range, NaN kept
+__global__ __launch_bounds__(256) void cast_rows_f16_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ y, long ldy, long M,
+                                                            int c8, unsigned long long* sat) {
+    const long total = M * c8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / c8;
+        const int c = (int)(idx - m * c8) * 8;
+        const u32x4 a = *(const u32x4*)(x + m * ldx + c), b = *(const u32x4*)(x + m * ldx + c + 4);
+        const float e0[4] = {__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
+        const float e1[4] = {__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+        count_f16_saturation(sat, e0);
+        count_f16_saturation(sat, e1);
+        const u32x2 h0 = pack4_f16_sat(e0), h1 = pack4_f16_sat(e1);
+        *(u32x4*)(y + m * ldy + c) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    }
+}
+
 __global__ void timestep_embedding_kernel(const long* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out,
                                           int B, int half) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,6 +144,19 @@ extern "C" int geo4d_tokens_from_ncthw(const float* src0, int C0, const float* s
         case GEO4D_BF16: hipLaunchKernelGGL(tokens_from_ncthw_kernel<bf16_t>, grid, dim3(256), 0, s, src0, C0, src1, C1, (bf16_t*)out, Cpad, B, T, HW); break;
         default: hipLaunchKernelGGL(tokens_from_ncthw_kernel<f16_t>, grid, dim3(256), 0, s, src0, C0, src1, C1, (f16_t*)out, Cpad, B, T, HW); break;
     }
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
+extern "C" int geo4d_cast_rows_f16(const float* x, long ldx, void* y, long ldy, long M, int C, unsigned long long* sat_count, void* stream) {
+    if (M <= 0 || C <= 0 || (C % 8) || (ldx % 4) || (ldy % 8) || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) {
+        geo4d_set_error("cast_rows_f16: C % 8 == 0, 16-byte aligned rows");
+        return GEO4D_EINVAL;
+    }
+    const long total = M * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(cast_rows_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)y, ldy, M, C / 8, sat_count);
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;
 }

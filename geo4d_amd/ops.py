@@ -681,6 +681,19 @@ def tokens_from_ncthw(src0, src1, cpad, dtype):
     return out
 
 
+def cast_f16(x, out=None):
+    """f32 rows [M, C] -> plain f16 rows (clamped, NaN kept): the two-pass GEMM's A operand made from a tensor without a normalising producer
+    (bf16x3m class "vaeup": the VAE decoder's stream in front of its upsampling convolutions)."""
+    lib = _lib.load()
+    _dev(x, "x")
+    assert x.dtype == torch.float32 and x.dim() == 2
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty((M, Cc), device=x.device, dtype=torch.float16)
+    _lib.check(lib.geo4d_cast_rows_f16(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), M, Cc, _ptr(SAT_COUNTER), _stream()), "geo4d_cast_rows_f16")
+    return out
+
+
 def concat_channels(a, b):
     lib = _lib.load()
     _dev(a, "a"); _dev(b, "b")

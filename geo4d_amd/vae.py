@@ -183,7 +183,11 @@ class AutoencoderKL(ParamTree):
                             v=(pack.pack_linear(sd[p + ".v.weight"], dt), f32(p + ".v.bias")),
                             o=(pack.pack_linear(sd[p + ".proj_out.weight"], dt), f32(p + ".proj_out.bias")))
             else:
-                P[p] = (pack.pack_conv2d(sd[p + ".weight"], dt), f32(p + ".bias"))
+                # class "vaeup" (round 6): the Upsample convolutions (nearest 2x folded into the gather) take the two-pass f16 form on an f16 copy
+                # of the decoder's stream - the decoder has no 50-step recurrence: its stream rounding is a one-off 2^-12 (round 5 judged this
+                # class together with the U-Net's streams and rejected both; measured alone: profiles/r06_vae_decode.md)
+                up2 = bool(dt.two_pass("vaeup") and self.presplit)
+                P[p] = ((pack.pack_conv2d_x2 if up2 else pack.pack_conv2d)(sd[p + ".weight"], dt), f32(p + ".bias"))
         P["head"] = (norm("decoder.norm_out"), pack.pack_conv2d(sd["decoder.conv_out.weight"], dt), f32("decoder.conv_out.bias"))
         # channel-mean head: mean_c(conv(x, W)_c + b_c) == conv(x, mean_c W_c) + mean_c b_c  (depth modality, test_geo4d.py:254-257)
         P["head_mean"] = (P["head"][0], pack.pack_conv2d(sd["decoder.conv_out.weight"].mean(0, keepdim=True), dt),
@@ -294,7 +298,8 @@ class AutoencoderKL(ParamTree):
             elif kind == "attn":
                 x = self._attn(P[p], x, n, H, W)
             else:
-                x, H, W = ops.conv2d(x, *P[p], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2, gn_stats=True)
+                a = ops.cast_f16(x) if ops.is_x2_weight(P[p][0]) else x
+                x, H, W = ops.conv2d(a, *P[p], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2, gn_stats=True)
         return x, H, W
 
     def _head(self, head, feat, F_, H, W, out, T, nchw_channels):

@@ -189,6 +189,11 @@ int geo4d_tokens_from_ncthw(const float* src0, int C0, const float* src1, int C1
 int geo4d_concat_channels(const void* a, long lda, int Ca, const void* b, long ldb, int Cb, void* out, long ldo, long M,
                           int dtype, void* stream);
 
+/* y = f16(x) row by row: the A operand of a dtype-4 (two-pass f16) geo4d_conv_gemm launch made from an f32 tensor that has no normalising
+ * producer in front of it - the VAE decoder's residual stream in front of its Upsample convolutions (ae_modules.py:111-127), bf16x3m class
+ * "vaeup". Values clamped to the finite f16 range, NaN kept; `sat_count` = optional debug counter of the clamp (NULL in production). C % 8 == 0. */
+int geo4d_cast_rows_f16(const float* x, long ldx, void* y, long ldy, long M, int C, unsigned long long* sat_count, void* stream);
+
 /* out[b] = [cos(t_b * f) | sin(t_b * f)]; replaces timestep_embedding (utils_diffusion.py:8-28). */
 int geo4d_timestep_embedding(const long* t, const float* freqs, float* out, int B, int dim, void* stream);
 

@@ -134,6 +134,27 @@ PY
     ( time GEO4D_TWO_PASS=$BASE,cattn,tattn timeout 1500 python -m pytest tests/test_fullsize_gpu.py tests/test_parity_gpu.py -m gpu -q -s -k "full_size or window_end_to_end or ddim_sampler" ) > $O/pytest_full.log 2>&1; echo "pytest rc=$?" >> $O/pytest_full.log
     grep -E "bf16x3m|passed|failed|rc=|Error|^FAILED" $O/pytest_full.log | cut -c1-520 | tail -20
     ;;
+  r6f)         # class vaeup (two-pass Upsample convs on an f16 copy of the decoder stream): decoder-alone parity vs the reference, decode ms, frames/s
+    BASE=conv3x3,vae3x3,tconv,ln,ff,attn,cattn,tattn
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for cls in $BASE $BASE,vaeup; do
+      ( GEO4D_TWO_PASS=$cls timeout 900 python -m pytest tests/test_fullsize_gpu.py tests/test_parity_gpu.py tests/test_sizes_gpu.py -m gpu -q -s -k "vae_decode or window_end_to_end or 50_step_window" ) > $O/pytest_$cls.log 2>&1; echo "pytest rc=$?" >> $O/pytest_$cls.log
+      echo "== $cls"; grep -E "bf16x3m|passed|failed|rc=|Error|^FAILED" $O/pytest_$cls.log | cut -c1-420 | tail -8
+    done
+    for i in 1 2; do
+      for cls in $BASE $BASE,vaeup; do
+        GEO4D_TWO_PASS=$cls timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_${cls}_$i.json 2> $O/bench_${cls}_$i.err; bl $O/bench_${cls}_$i.json "$cls run $i:"
+      done
+    done
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
