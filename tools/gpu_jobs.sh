@@ -155,6 +155,29 @@ PY
       done
     done
     ;;
+  r6g)         # re-measure the tuning table for the two-pass launches (their A rows are 2-byte now) + the new f16-row shapes; A/B old vs new table
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_before.json
+    timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_old_1.json 2> $O/bench_old_1.err; bl $O/bench_old_1.json "old table run 1:"
+    timeout 1500 python tools/tune_gemm.py $O/gfx950.json --keep --drop-prefix=4/ bf16x3m > $O/tune.log 2>&1; show $O/tune.log | tail -3
+    if [ -s $O/gfx950.json ]; then
+      cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_new_1.json 2> $O/bench_new_1.err; bl $O/bench_new_1.json "new table run 1:"
+      cp $O/gfx950_before.json geo4d_amd/tuning/gfx950.json
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_old_2.json 2> $O/bench_old_2.err; bl $O/bench_old_2.json "old table run 2:"
+      cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/bench_new_2.json 2> $O/bench_new_2.err; bl $O/bench_new_2.json "new table run 2:"
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -4 $O/smoke.log
+    fi
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-end evidence in ONE gpurun call (round 5 form, ~16 min): the whole GPU suite (-s: the parity numbers land in the log), smoke(), the
-# DEFAULT bench line (what the driver runs, with fewer steps), a same-box A/B against the round-4 end state (gpurun_ab_r4/ = `git archive
-# c2b5be3`, built ON the box), a kernel trace of the bench split into phases, three PMC passes over one U-Net forward of the headline
+# Round-end evidence in ONE gpurun call (round 6 form, ~16 min): the whole GPU suite (-s: the parity numbers land in the log), smoke(), the
+# DEFAULT bench line (what the driver runs, with fewer steps), a same-box A/B against the round-5 end state (gpurun_ab_r5/ = `git archive
+# 1f11639`, built in the container), a kernel trace of the bench split into phases, three PMC passes over one U-Net forward of the headline
 # mode, the GEMM census (three-pass, two-pass, vendor single-pass bf16) and the attention bench. Raw profiler output stays in /tmp;
 # summaries land in gpurun_out/final/ (copy what should be judged into profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -14,18 +14,17 @@ export TMPDIR=/tmp
 grep -E "passed|failed|rc=|^FAILED|^ERROR" $O/pytest.log | tail -6
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
 ( time timeout 900 python bench.py --steps 5 --warmup 2 ) > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err; cut -c1-400 $O/bench.json
-# same-box A/B against the round-4 end state
-if [ -d $R/gpurun_ab_r4 ]; then
-  cd $R/gpurun_ab_r4 && ( time make -j64 > $O/build_r4.log 2>&1 ) 2>&1 | grep real
+# same-box A/B against the round-5 end state (gpurun_ab_r5/ = `git archive 1f11639`, library built in the container: it travels with the snapshot)
+if [ -f $R/gpurun_ab_r5/geo4d_amd/csrc/libgeo4d_hip.so ]; then
   for i in 1 2; do
-    cd $R/gpurun_ab_r4 && timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode > $O/ab_r4_$i.json 2> $O/ab_r4_$i.err
-    cd $R && timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/ab_r5_$i.json 2> $O/ab_r5_$i.err
+    cd $R/gpurun_ab_r5 && timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/ab_r5_$i.json 2> $O/ab_r5_$i.err
+    cd $R && timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg > $O/ab_r6_$i.json 2> $O/ab_r6_$i.err
   done
   cd $R && python - <<PY
 import json
-for n in ("ab_r4_1", "ab_r5_1", "ab_r4_2", "ab_r5_2"):
+for n in ("ab_r5_1", "ab_r6_1", "ab_r5_2", "ab_r6_2"):
     try:
-        d = json.load(open("$O/%s.json" % n)); print(n, d["dtype"], round(d["value"], 3), "frames/s", {k: round(v) for k, v in d["split_ms_per_step"].items()}, "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+        d = json.loads([l for l in open("$O/%s.json" % n) if l.startswith("{")][-1]); print(n, d["dtype"], round(d["value"], 3), "frames/s", {k: round(v) for k, v in d["split_ms_per_step"].items()}, "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
     except Exception as e:
         print(n, "failed", e)
 PY
@@ -47,4 +46,4 @@ cd $R
 timeout 300 python tools/gemm_bench.py --dtype bf16x3 --presplit --iters 10 --vendor > $O/gemm_x3.log 2>&1; tail -2 $O/gemm_x3.log
 timeout 300 python tools/gemm_bench.py --dtype f16x2 --iters 10 > $O/gemm_x2.log 2>&1; tail -2 $O/gemm_x2.log
 timeout 300 python tools/gemm_bench.py --dtype bf16 --iters 10 --vendor > $O/gemm_bf16_vendor.log 2>&1; tail -2 $O/gemm_bf16_vendor.log
-timeout 200 python tools/attn_bench.py bf16 bf16x3 > $O/attn.log 2>&1; grep "2560\|forward" $O/attn.log | grep "v4\|v3 \|v1 " | tail -8
+timeout 200 python tools/attn_bench.py bf16 f16 bf16x3 > $O/attn.log 2>&1; grep "2560\|forward" $O/attn.log | grep "v4\|v3 \|v1 " | tail -8
