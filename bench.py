@@ -596,6 +596,17 @@ def main():
             cm = clip_mode(a2, model, pvae, dev, rank, world)
         except Exception as e:       # noqa: BLE001 - whatever it is, the line still goes out
             cm = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            # the ranks must AGREE that the leg succeeded before anything else is exchanged: a rank whose leg raised while its
+            # peers sat in one of clip_mode's collectives leaves those peers to the process group's timeout (geo4d_amd.dist: 600 s), after
+            # which they raise too; whoever gets here votes, and one failure anywhere marks the leg failed on every rank
+            try:
+                ok = torch.tensor([0.0 if "error" in cm else 1.0], device=dev)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+                if float(ok.item()) == 0.0 and "error" not in cm:
+                    cm = {"error": "the clip leg failed on another rank"}
+            except Exception as e:   # noqa: BLE001 - the communicator is gone (a peer timed out): report, do not hang
+                cm = {"error": f"clip leg: ranks could not agree ({type(e).__name__}: {e})"}
         if rank == 0:
             res["clip_mode"] = cm if "error" in cm else {k: cm[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "scaling", "phase_seconds",
                                                                            "denoised_frames_per_sec", "alignment_outputs_finite", "alignment_vs_scene_truth", "data")} | {

@@ -33,7 +33,10 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a collective that a peer never joins (a rank-specific failure) must end in an error, not a hang: GEO4D_DIST_TIMEOUT_S (default 600 s)
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("GEO4D_DIST_TIMEOUT_S", "600"))))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local

@@ -183,13 +183,13 @@ def _oracle_objective(data, state, local_groups=None, pose_terms=True):
     return f
 
 
-def _align_worker(rank, world, port, q):
+def _align_worker(rank, world, port, q, exchange="halo", n=11):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from geo4d_amd import dist as gd
     from geo4d_amd.align_dist import AlignShard
     gd.init_from_env(backend="gloo")
-    groups, data, P, state = _align_problem()
-    shard = AlignShard(groups, P["im_depthmaps"].shape[0])
+    groups, data, P, state = _align_problem(n=n)
+    shard = AlignShard(groups, P["im_depthmaps"].shape[0], exchange=exchange)
     local = _oracle_objective(data, state, local_groups=shard.local_groups, pose_terms=shard.primary)
     first = {}
 
@@ -208,15 +208,29 @@ def _align_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_alignment_sharded_over_two_ranks_equals_single_rank():
-    """Window blocks on 2 ranks, one all-reduce of [loss | small gradients | depth gradients of the shared images] per iteration:
-    the first loss / gradients and 8 Adam iterations equal the un-sharded objective to fp32 round-off; depth maps of images that only
-    one rank touches are final on that rank alone and assembled by gather_depthmaps."""
+import pytest
+
+
+@pytest.mark.parametrize("world,exchange,n", [(2, "halo", 11), (2, "allreduce", 11), (3, "halo", 7)])
+def test_alignment_sharded_over_two_ranks_equals_single_rank(world, exchange, n):
+    """Window blocks on 2 (3) ranks; per iteration one small all-reduce of [loss | small gradients] and the depth gradients of the shared
+    images by the neighbour halo exchange (round 6) or, as in rounds 3-5, inside that all-reduce: the first loss / gradients and 8 Adam
+    iterations equal the un-sharded objective to fp32 round-off; depth maps of images that only one rank touches are final on that
+    rank alone and assembled by gather_depthmaps. world 3 with n = 7 images (4 windows of 4 at stride 1, blocks of 2 / 1 / 1): images
+    2 and 3 are touched by ALL THREE ranks - the partial rows are added in ascending rank order on each of them."""
     from geo4d_amd.align_dist import AlignShard, partition_windows
     assert [partition_windows(30, r, 8) for r in range(8)][0] == [0, 1, 2, 3] and sum(len(partition_windows(30, r, 8)) for r in range(8)) == 30
     s8 = AlignShard([list(range(4 * w, 4 * w + 16)) for w in range(29)], 128, rank=3, world=8)
     assert len(s8.shared) == 7 * 12 and s8.local_groups == partition_windows(29, 3, 8)      # 12 images per block boundary
-    groups, data, P, state = _align_problem()
+    # halo: rank 3 of 8 talks to its two neighbours only, 12 images each; per iteration it sends 24 rows instead of the 84 of the all-reduce
+    assert s8.peers == [2, 4] and [len(s8.peer_images[q]) for q in s8.peers] == [12, 12] and all(len(t) <= 2 for t in s8.touch)
+    HW = 320 * 512
+    assert s8.bytes_per_iteration(HW, 1000) == 4 * 1001 + 4 * HW * 24
+    assert AlignShard(s8.groups, 128, rank=3, world=8, exchange="allreduce").bytes_per_iteration(HW, 1000) == 4 * (1001 + 84 * HW)
+    if world == 3:
+        s3 = [AlignShard([list(range(s, s + 4)) for s in range(4)], 7, rank=r, world=3) for r in range(3)]
+        assert s3[0].touch[2] == (0, 1) and s3[0].touch[3] == (0, 1, 2) and s3[1].peers == [0, 2] and (0, 1, 2) in s3[2].sets
+    groups, data, P, state = _align_problem(n=n)
     ref_obj = _oracle_objective(data, state)
     ref_loss, ref_grads = ref_obj(P)
     ref_P = {k: v.clone() for k, v in P.items()}
@@ -224,20 +238,22 @@ def test_alignment_sharded_over_two_ranks_equals_single_rank():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_align_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_align_worker, args=(r, world, port, q, exchange, n)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
     [p.join(timeout=60) for p in procs]
     res = [(r, lg, sh, dict(loss=f["loss"], grads={k: torch.from_numpy(v) for k, v in f["grads"].items()}), ls,
             {k: torch.from_numpy(v) for k, v in Pr.items()}, torch.from_numpy(tab)) for r, lg, sh, f, ls, Pr, tab in res]
-    n = P["im_depthmaps"].shape[0]
-    assert res[0][1] + res[1][1] == list(range(len(groups))) and res[0][2] == res[1][2] and 0 < len(res[0][2]) < n
+    n_img = P["im_depthmaps"].shape[0]
+    assert sum((r[1] for r in res), []) == list(range(len(groups))) and all(r[2] == res[0][2] for r in res) and 0 < len(res[0][2]) <= n_img
     shared = res[0][2]
+    touch = AlignShard(groups, n_img, rank=0, world=world).touch
     for rank, local, _, first, losses, Pr, tab in res:
         assert abs(first["loss"] - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
         for k, gref in ref_grads.items():
-            if k == "im_depthmaps":      # complete on every rank for the shared images, complete on the owning rank for the others
-                assert torch.allclose(first["grads"][k][shared], gref[shared], rtol=1e-4, atol=1e-7), k
+            if k == "im_depthmaps":      # complete on every TOUCHING rank for the shared images (all-reduce form: on every rank), complete on the owning rank for the others
+                rows = [i for i in shared if exchange == "allreduce" or rank in touch[i]]
+                assert rows and torch.allclose(first["grads"][k][rows], gref[rows], rtol=1e-4, atol=1e-7), k
             else:
                 assert torch.allclose(first["grads"][k], gref, rtol=1e-4, atol=1e-7), k
         assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 1e-5 * abs(ref_losses[0])
@@ -245,7 +261,7 @@ def test_alignment_sharded_over_two_ranks_equals_single_rank():
             assert torch.allclose(Pr[k], v, rtol=2e-4, atol=2e-6), (rank, k, (Pr[k] - v).abs().max())
         assert torch.equal(tab, torch.arange(len(groups) * 3, dtype=torch.float32).reshape(-1, 3) + 1)
     for k in ref_P:                          # the replicated parameters are bit-identical across ranks (no broadcast needed)
-        assert torch.equal(res[0][5][k], res[1][5][k]), k
+        assert all(torch.equal(res[0][5][k], r[5][k]) for r in res[1:]), k
 
 
 def test_alignment_shard_falls_back_when_windows_fewer_than_ranks():
