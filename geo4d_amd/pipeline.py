@@ -175,7 +175,7 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
 def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_length=16, seed=123, ddim_steps=50, ddim_eta=0.0,
              unconditional_guidance_scale=1.0, fs=24, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
              prompts=("Output a video that assigns each 3D location in the world a consistent color.",),
-             synthesize=None, gather=True, with_cameras=False, decode="local", decoder=None, **kwargs):
+             synthesize=None, gather=True, with_cameras=False, decode="local", decoder=None, window_batch=1, **kwargs):
     """The window loop of ``run_inference`` (test_geo4d.py:396-443), data-parallel over windows.
 
     ``videos_all`` [1,3,T,H,W] in [-1,1]; ``context`` = cross-attention context [1, 77+16*video_length, D] (the OpenCLIP /
@@ -193,7 +193,13 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
     "sharded" — windows are processed in rounds of ``world``; each round's latents are broadcast by their owners (2.6 MB each)
     and every window's 4 x T frame-modalities are decoded FRAME-SHARDED over all ranks with an all-gather along the frame axis
     (decode_modalities_sharded), which keeps all GPUs busy in a ragged last round (14 windows on 8 GPUs) and for a single window.
-    Every rank ends up with every window either way."""
+    Every rank ends up with every window either way.
+
+    ``window_batch`` (round 6): a rank denoises this many of ITS windows as ONE batch (eta = 0 only). Windows are independent, and at B = 1
+    the U-Net's levels 1-3 leave most of the 256 CUs idle (tiles < CUs): two windows per DDIM step take 1.64x the time of one on an
+    MI355X (profiles/r06_window_batch.md: 7.78 vs 6.52 denoised frames/s). Noise, VAE-encode sampling and conditioning stay seeded /
+    computed PER WINDOW, so a window's result does not depend on what it was batched with beyond fp32 round-off (GEMM tile choice follows M).
+    In the sharded-decode mode a round then covers world x window_batch windows, rank r owning the r-th run of window_batch."""
     from . import dist as gdist
     synthesize = synthesize or image_guided_synthesis
     B, C, T, H, W = videos_all.shape
@@ -227,15 +233,46 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
         assert maps.shape[1] == 1, "only support variants size = 1"
         return maps[:, 0]
 
+    wb = 1 if ddim_eta > 0.0 else max(1, int(window_batch))
+
+    def window_group(wis, decode_here):
+        """Several of this rank's windows as ONE batch through the sampler (and the decoder): [len(wis), 11 | 16, T, ...]."""
+        if len(wis) == 1:
+            return one_window(wis[0], decode_here)
+        vids, xs, zs, ctxs = [], [], [], []
+        for wi in wis:
+            videos = videos_all[:, :, slices[wi]].clone()
+            wseed = (int(seed) * 1000003 + wi) % (2 ** 63 - 1)
+            xs.append(torch.randn(noise_shape, generator=torch.Generator().manual_seed(wseed)))
+            ctxs.append(context(videos) if callable(context) else context)
+            if model.model.conditioning_key == "hybrid":
+                with torch.random.fork_rng(devices=[]):
+                    torch.manual_seed(wseed)                           # the window's own posterior-sampling noise, as in one_window
+                    zs.append(get_latent_z(model, videos))
+            vids.append(videos)
+        cond = {"c_crossattn": [torch.cat(ctxs, 0)]}
+        if zs:
+            cond["c_concat"] = [torch.cat(zs, 0)]
+        extra = {} if decode_here else {"decode": False}
+        maps = synthesize(model, list(prompts) * len(wis), torch.cat(vids, 0), [len(wis)] + noise_shape[1:], n_samples=1, ddim_steps=ddim_steps,
+                          ddim_eta=ddim_eta, unconditional_guidance_scale=unconditional_guidance_scale, fs=fs, timestep_spacing=timestep_spacing,
+                          guidance_rescale=guidance_rescale, pointmap_vae=pointmap_vae, cond=cond, x_T=torch.cat(xs, 0).to(videos_all.device),
+                          **extra, **kwargs)
+        assert maps.shape[1] == 1, "only support variants size = 1"
+        return maps[:, 0]
+
     if decode == "sharded" and world > 1:
         if B != 1:
             raise ValueError("sharded decode handles one clip at a time")
         nwin = len(slices)
-        for k in range(0, nwin, world):
-            lat = one_window(k + rank, False).float().contiguous() if k + rank < nwin else None
-            for wi in range(k, min(k + world, nwin)):
-                buf = lat if wi - k == rank else videos_all.new_empty(noise_shape, dtype=torch.float32)
-                gdist.broadcast_from(buf, wi - k)
+        per_round = world * wb
+        for k in range(0, nwin, per_round):
+            mine = [k + rank * wb + j for j in range(wb) if k + rank * wb + j < nwin]
+            lat = window_group(mine, False).float().contiguous() if mine else None
+            for wi in range(k, min(k + per_round, nwin)):
+                owner, j = divmod(wi - k, wb)
+                buf = lat[j:j + 1].contiguous() if owner == rank else videos_all.new_empty(noise_shape, dtype=torch.float32)
+                gdist.broadcast_from(buf, owner)
                 maps = decode_modalities_sharded(model, buf, pointmap_vae, rank=rank, world=world, decoder=decoder)
                 local.append(maps)
                 if with_cameras:
@@ -246,11 +283,12 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
         return (slices, *out)
     if decode not in ("local", "sharded"):
         raise ValueError(f"run_clip: decode={decode!r} (expected 'local' or 'sharded')")
-    for wi in gdist.shard_windows(len(slices), rank, world):
-        maps = one_window(wi, True)
+    mine = gdist.shard_windows(len(slices), rank, world)
+    for i in range(0, len(mine), wb):
+        maps = window_group(mine[i:i + wb], True)
         local.append(maps)
         if with_cameras:
-            traj.append(cameras(maps))
+            traj.extend(cameras(maps[j:j + 1]) for j in range(maps.shape[0]))
     like = videos_all.new_zeros((0, 11, video_length, H, W), dtype=torch.float32)
     local = torch.cat(local, 0) if local else like
     out = [local]

@@ -106,6 +106,62 @@ def test_run_clip_world2_equals_world1():
         assert torch.equal(torch.from_numpy(maps), maps1), f"rank {rank}: sharded clip differs from the single-process clip"
 
 
+def _stub_synth_rows(model, prompts, videos, noise_shape, n_samples=1, x_T=None, cond=None, decode=True, **kw):
+    """Like _stub_synth but sample-wise (what the real sampler is): row b depends on window b's frames, noise, context and video latent only."""
+    B, _, T, h, w = noise_shape
+    if "c_concat" not in cond:           # image_guided_synthesis encodes the window itself when the caller did not (pipeline.py: get_latent_z)
+        cond = dict(cond, c_concat=[model.encode_first_stage(videos)])
+    assert videos.shape[0] == B and x_T.shape[0] == B and cond["c_crossattn"][0].shape[0] == B and cond["c_concat"][0].shape[0] == B
+    v = videos.mean(dim=(1, 3, 4)).reshape(B, 1, T, 1, 1)
+    per = (x_T.mean(dim=(1, 2, 3, 4)) + cond["c_crossattn"][0].mean(dim=(1, 2)) + cond["c_concat"][0].mean(dim=(1, 2, 3, 4))).reshape(B, 1, 1, 1, 1)
+    lat = torch.zeros((B, 16, T, h, w)) + v + per
+    return (_stub_decoder(model, lat) if decode else lat)[:, None]
+
+
+class _StubModelEnc(_StubModel):
+    @staticmethod
+    def encode_first_stage(videos):      # "posterior sample": the window's frames + noise from the CPU RNG run_clip seeds per window
+        b, _, t, H, W = videos.shape
+        return videos.mean(dim=1, keepdim=True).expand(b, 4, t, H, W)[..., ::8, ::8] + torch.randn((b, 4, t, H // 8, W // 8))
+
+
+def _batch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from geo4d_amd import dist as gd
+    from geo4d_amd.pipeline import run_clip
+    gd.init_from_env(backend="gloo")
+    video = torch.arange(1 * 3 * 38 * 16 * 16, dtype=torch.float32).reshape(1, 3, 38, 16, 16) / 1e4
+    outs = [run_clip(_StubModelEnc, video, torch.ones((1, 333, 8)), ddim_steps=2, synthesize=_stub_synth_rows, decode=d, decoder=_stub_decoder,
+                     window_batch=wb)[1] for d in ("local", "sharded") for wb in (2, 3)]
+    q.put((rank, [o.numpy() for o in outs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_clip_window_batch_is_invisible_in_the_result():
+    """Round 6: run_clip(window_batch = k) denoises k of a rank's windows as one batch. Noise, VAE-encode sampling and conditioning stay per
+    window, so with a sample-wise sampler the result is IDENTICAL to window_batch = 1 - on one rank (7 windows: groups 2 + 2 + 2 + 1 and
+    3 + 3 + 1) and on two ranks in both decode modes (sharded: rounds of world x window_batch windows, rank r owning the r-th run)."""
+    from geo4d_amd.pipeline import run_clip
+    video = torch.arange(1 * 3 * 38 * 16 * 16, dtype=torch.float32).reshape(1, 3, 38, 16, 16) / 1e4
+    run = lambda wb: run_clip(_StubModelEnc, video, torch.ones((1, 333, 8)), ddim_steps=2, synthesize=_stub_synth_rows, window_batch=wb)
+    slices, ref = run(1)
+    assert len(slices) == 7 and ref.shape == (7, 11, 16, 16, 16) and len({float(ref[i].mean()) for i in range(7)}) == 7
+    for wb in (2, 3, 8):
+        assert torch.equal(run(wb)[1], ref), wb
+    assert torch.equal(run_clip(_StubModelEnc, video, torch.ones((1, 333, 8)), ddim_steps=2, ddim_eta=1.0, synthesize=_stub_synth_rows, window_batch=2)[1], ref)   # eta > 0: one window at a time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    for rank, outs in res:
+        for o in outs:
+            assert torch.equal(torch.from_numpy(o), ref), f"rank {rank}"
+
+
 def test_shard_tables():
     from geo4d_amd.dist import frame_shard, shard_windows, window_owner_table
     assert [frame_shard(16, r, 8) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]

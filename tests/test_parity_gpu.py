@@ -336,6 +336,27 @@ def test_run_clip_windows(dev):
     assert torch.equal(direct[:, 0], maps[0:1])
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16x3m", 1e-3)])
+def test_run_clip_window_batch_matches_one_window_at_a_time(dev, mode, tol):
+    """Round 6: run_clip(window_batch = 2) denoises and decodes two of a rank's windows as one batch (levels 1-3 of the U-Net cannot fill
+    the chip at one window). Per-window noise / VAE-encode sampling / conditioning are unchanged, so every window's maps equal the
+    one-at-a-time run up to what GEMM tile choice (it follows M) does to fp32 summation order - the mode's own rounding level; the
+    cameras follow; a ragged last group (3 windows: 2 + 1) is covered."""
+    from geo4d_amd.pipeline import run_clip
+    m, u, _ = _diffusion(dev, mode)
+    gen = torch.Generator().manual_seed(18)
+    video = (torch.rand((1, 3, 22, 64, 64), generator=gen) * 2 - 1).to(dev)
+    ctx = torch.randn((1, 77 + 16 * 16, u["unet_config"]["context_dim"]), generator=gen).to(dev)
+    kw = dict(ddim_steps=3, seed=77, with_cameras=True)
+    slices, one, traj1 = run_clip(m, video, ctx, window_batch=1, **kw)
+    _, two, traj2 = run_clip(m, video, lambda frames: ctx, window_batch=2, **kw)
+    assert [(s.start, s.stop) for s in slices] == [(0, 16), (4, 20), (6, 22)] and one.shape == two.shape == (3, 11, 16, 64, 64)
+    errs = [rel(two[i], one[i]) for i in range(3)]
+    print(f"[run_clip window_batch 2 vs 1] mode={mode} per-window rel_l2 {['%.2e' % e for e in errs]} (tol {tol:.0e})")
+    assert max(errs) < tol and torch.isfinite(two).all()
+    assert traj2.shape == (3, 16, 4, 4) and torch.allclose(traj2, traj1, atol=50 * tol)
+
+
 def test_plucker_cameras_vs_reference_golden(dev):
     """raymap_to_camera_matrix on the device (csrc/rays.hip) vs matrices produced by the reference's own
     functions (fixtures), vs the fp64 oracle on a larger window taken as channel views of a decoded [1,11,T,H,W] tensor, and on
