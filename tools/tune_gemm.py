@@ -19,7 +19,8 @@ def main():
     old = dict(ops._tune_table())
     keep = "--keep" in sys.argv          # --keep: only shapes MISSING from the table are measured (a new mode's launches), the rest keep their entry
     drop = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--drop-prefix=")]      # with --keep: forget the entries whose key starts with this (e.g. 4/ = the two-pass f16 launches) so that they are re-measured
-    sys.argv = [a for a in sys.argv if not a.startswith("--drop-prefix=")]
+    batches = [int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--batch=")] or [1]      # --batch=2: the shapes of two windows per step (run_clip window_batch)
+    sys.argv = [a for a in sys.argv if not a.startswith("--drop-prefix=") and not a.startswith("--batch=")]
     for pre in drop:
         for k in [k for k in ops._tune_table() if k.startswith(pre)]:
             del ops._tune_table()[k]
@@ -32,14 +33,15 @@ def main():
         model, pvae = bench.build(dtype, dev)
         T, h, w = 16, 40, 64
         g = torch.Generator().manual_seed(0)
-        x = torch.randn((1, 16, T, h, w), generator=g).to(dev)
-        zc = torch.randn((1, 4, T, h, w), generator=g).to(dev)
-        ctx = torch.randn((1, 77 + 16 * T, 1024), generator=g).to(dev)
-        t = torch.tensor([500], device=dev)
-        y = model.apply_model(x, t, {"c_crossattn": [ctx], "c_concat": [zc]}, fs=torch.tensor([24], device=dev))
         from geo4d_amd.pipeline import decode_modalities
-        decode_modalities(model, y, pvae)
-        torch.cuda.synchronize()
+        for nb in batches:
+            x = torch.randn((nb, 16, T, h, w), generator=g).to(dev)
+            zc = torch.randn((nb, 4, T, h, w), generator=g).to(dev)
+            ctx = torch.randn((nb, 77 + 16 * T, 1024), generator=g).to(dev)
+            t = torch.full((nb,), 500, device=dev)
+            y = model.apply_model(x, t, {"c_crossattn": [ctx], "c_concat": [zc]}, fs=torch.full((nb,), 24, device=dev))
+            decode_modalities(model, y, pvae)
+            torch.cuda.synchronize()
         del model, pvae
     fresh = {k: v for k, v in ops._TUNE.items() if (not keep or k not in old)}
     changed = sum(1 for k, v in fresh.items() if old.get(k) != v)
