@@ -525,6 +525,88 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const geo4d_conv_gem
     for (int j = 0; j < 8; ++j) store_out(p.O, bz * p.o_bs + (long)m * p.ldo + n + j, e[j], p.out_dtype);
 }
 
+// The same reduction for launches that ALSO emit the consumer GroupNorm's column sums (round 6; geo4d_conv_gemm_t.gn_colsum on a split-K
+// launch of the second / third generation): a workgroup owns RB rows x (256 / RB) groups of 8 columns, thread (r, cg) finishes 8 outputs of row r
+// exactly like splitk_reduce_kernel (same summation order, same epilogue order: same bits), then the RB rows of every column are added in a
+// fixed tree (xor shuffles inside the wave, the 4 waves through LDS in wave order) into gn_colsum[M / RB][N][2] = (sum, sum of squares).
+// batch 1, M % RB == 0, N % (8 * 256 / RB) == 0, f32 rows (splitk_colsum_rows below).
+template <typename T, int RB>
+__global__ __launch_bounds__(256) void splitk_reduce_colsum_kernel(const geo4d_conv_gemm_t p, int splits) {
+    constexpr int CG = 256 / RB;                 // 8-column groups per workgroup
+    __shared__ float part[4][CG * 8][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = tid / CG, cg = tid % CG;
+    const int tiles_n = p.N / (8 * CG);
+    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x - bm * tiles_n;
+    const int m = bm * RB + r, n = (bn * CG + cg) * 8;
+    const long slab = (long)p.M * p.N;
+    const float* src = (const float*)p.workspace + (long)m * p.N + n;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    for (int z = 0; z < splits; ++z) {
+        const f32x4 a = *(const f32x4*)(src + z * slab), b = *(const f32x4*)(src + z * slab + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e[j] += a[j]; e[4 + j] += b[j]; }
+    }
+    const long rboff = p.rowbias ? (long)(m / p.rowbias_div) * (p.ldrb ? p.ldrb : (long)p.N) : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = e[j] * p.alpha;
+        if (p.bias) v += p.bias[n + j];
+        if (p.rowbias) v += p.rowbias[rboff + n + j];
+        if (p.R) v += ((const float*)p.R)[(long)m * p.ldr + n + j];
+        e[j] = v;
+    }
+    *(f32x4*)((float*)p.O + (long)m * p.ldo + n) = f32x4{e[0], e[1], e[2], e[3]};
+    *(f32x4*)((float*)p.O + (long)m * p.ldo + n + 4) = f32x4{e[4], e[5], e[6], e[7]};
+    float q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = e[j] * e[j];
+    // rows of one wave: lanes that differ by a multiple of CG hold the same columns
+#pragma unroll
+    for (int o = CG; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { e[j] += __shfl_xor(e[j], o); q[j] += __shfl_xor(q[j], o); }
+    }
+    if (lane < CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { part[wave][lane * 8 + j][0] = e[j]; part[wave][lane * 8 + j][1] = q[j]; }
+    }
+    __syncthreads();
+    if (tid < CG * 8) {
+        float s0 = part[0][tid][0], s1 = part[0][tid][1];
+        for (int w2 = 1; w2 < 4; ++w2) { s0 += part[w2][tid][0]; s1 += part[w2][tid][1]; }      // fixed wave order
+        float* dst = p.gn_colsum + ((long)bm * p.N + bn * CG * 8 + tid) * 2;
+        dst[0] = s0; dst[1] = s1;
+    }
+}
+// rows per gn_colsum entry a split-K launch of the second / third generation emits through splitk_reduce_colsum_kernel (0 = it cannot): 32, or 8
+// where a frame's rows are a multiple of 8 but not of 32 (the 5 x 8 level: per-frame GroupNorms need blocks that do not straddle frames)
+inline int splitk_colsum_rows(const geo4d_conv_gemm_t& p, int sp) {
+    if (sp <= 1 || p.batch != 1 || p.act != 0 || p.o_split || p.out_nchw || p.out_dtype != GEO4D_F32 || p.bias_per_row || (p.ldo & 3) || ((uintptr_t)p.O % 16) ||
+        (p.R && ((uintptr_t)p.R % 4))) return 0;
+    const int hw = p.Hout * p.Wout;
+    if (hw % 32 == 0 && p.M % 32 == 0 && p.N % 64 == 0) return 32;
+    if (hw % 8 == 0 && p.M % 8 == 0 && p.N % 256 == 0) return 8;
+    return 0;
+}
+// the reduce launch of a split-K GEMM (every generation's launcher ends here): with gn_colsum, the column-sum form
+template <typename T>
+int launch_splitk_reduce(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
+    if (p.gn_colsum) {
+        const int rows = splitk_colsum_rows(p, splits);
+        if (rows == 32) hipLaunchKernelGGL((splitk_reduce_colsum_kernel<T, 32>), dim3((unsigned)((p.M / 32) * (p.N / 64))), dim3(256), 0, stream, p, splits);
+        else if (rows == 8) hipLaunchKernelGGL((splitk_reduce_colsum_kernel<T, 8>), dim3((unsigned)((p.M / 8) * (p.N / 256))), dim3(256), 0, stream, p, splits);
+        else { geo4d_set_error("conv_gemm: gn_colsum on a split-K launch needs batch 1, f32 rows, no activation, frame rows % 8 == 0 (geo4d_conv_gemm_colsum_rows)"); return GEO4D_EINVAL; }
+    } else {
+        const long tot = (long)p.batch * p.M * (p.N / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, p, splits);
+    }
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int ST, int HOT>
 int launch_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     constexpr int smem = smem_bytes<BM, BN, WM, WN, ST>();

@@ -746,11 +746,7 @@ int launch_v2_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream)
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, stream, p, splits, tiles_mn);
     GEO4D_CHECK_LAUNCH();
-    if (splits > 1) {
-        const long tot = (long)p.batch * p.M * (p.N / 8);
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, p, splits);
-        GEO4D_CHECK_LAUNCH();
-    }
+    if (splits > 1) return launch_splitk_reduce<T>(p, splits, stream);
     return GEO4D_OK;
 }
 
@@ -826,6 +822,9 @@ int launch_v2_typed(const geo4d_conv_gemm_t& p_in, hipStream_t stream) {
             }
             sp = p.split_k;
         }
+        if (p.gn_colsum && sp > 1) {      // split-K: the sums come from the reduce launch (gemm_kernel.h splitk_reduce_colsum_kernel)
+            if (!splitk_colsum_rows(p, sp)) { geo4d_set_error("conv_gemm: this split-K launch cannot emit gn_colsum (geo4d_conv_gemm_colsum_rows)"); return GEO4D_EINVAL; }
+        } else
         if (p.gn_colsum && (!colsum_fast_ok(p, sp) || v2_wave_rows(p.tile_hint) == 0 || p.M % v2_wave_rows(p.tile_hint) || ((uintptr_t)p.gn_colsum % 16))) {
             geo4d_set_error("conv_gemm: gn_colsum on tile hints 22..28 needs the plain f32-row epilogue (no activation / split-K / o_split / batch) and M % wave-tile rows == 0 (geo4d_conv_gemm_colsum_rows)");
             return GEO4D_EINVAL;

@@ -494,11 +494,7 @@ int launch_v3_kernel(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream)
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, p, splits, tiles_mn);
     GEO4D_CHECK_LAUNCH();
-    if (splits > 1) {
-        const long tot = (long)p.batch * p.M * (p.N / 8);
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, p, splits);
-        GEO4D_CHECK_LAUNCH();
-    }
+    if (splits > 1) return launch_splitk_reduce<T>(p, splits, stream);
     return GEO4D_OK;
 }
 
@@ -566,6 +562,7 @@ bool v3_native(const geo4d_conv_gemm_t& p, int sp) {
 template <typename T>
 int colsum_rows_v23(const geo4d_conv_gemm_t& p) {
     const int sp = p.split_k > 1 ? p.split_k : 1;
+    if (sp > 1) return (p.gn_colsum == nullptr || ((uintptr_t)p.gn_colsum % 8) == 0) ? splitk_colsum_rows(p, sp) : 0;     // from the reduce launch
     int rows = 0;
     if (p.tile_hint >= 71 && p.tile_hint <= 74) rows = v3_native<T>(p, sp) ? v3_wave_rows(p.tile_hint) : v2_wave_rows(v2_effective_hint<T>(v3_fallback_hint(p.tile_hint)));
     else rows = v2_wave_rows(v2_effective_hint<T>(p.tile_hint));
@@ -601,6 +598,9 @@ int launch_v3_typed(const geo4d_conv_gemm_t& p, hipStream_t stream) {
             q.tile_hint = v3_fallback_hint(p.tile_hint);      // (every tile sums in the same order: same bits)
             return launch_v2_typed<T>(q, stream);
         }
+        if (p.gn_colsum && sp > 1) {      // split-K: the sums come from the reduce launch (gemm_kernel.h splitk_reduce_colsum_kernel)
+            if (!splitk_colsum_rows(p, sp)) { geo4d_set_error("conv_gemm: this split-K launch cannot emit gn_colsum (geo4d_conv_gemm_colsum_rows)"); return GEO4D_EINVAL; }
+        } else
         if (p.gn_colsum && (!colsum_fast_ok(p, sp) || p.M % v3_wave_rows(p.tile_hint) || ((uintptr_t)p.gn_colsum % 16))) {
             geo4d_set_error("conv_gemm: gn_colsum on tile hints 71..74 needs the plain f32-row epilogue (no activation / split-K / o_split / batch) and M % wave-tile rows == 0 (geo4d_conv_gemm_colsum_rows)");
             return GEO4D_EINVAL;

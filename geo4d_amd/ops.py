@@ -187,6 +187,7 @@ def _env_level(name, default):
 
 
 GN_FUSED_STATS = _env_level("GEO4D_GN_FUSED", 1)
+SPLITK_COLSUM = _env_level("GEO4D_SPLITK_COLSUM", 1)       # 0: split-K launches leave the GroupNorm statistics to the GroupNorm (the state before round 6)
 TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) of every shape autotuned in this process (tools/tune_gemm.py prints it)
 DEBUG_ABLATE = _env_level("GEO4D_DEBUG_ABLATE", 0)       # tests / A-B runs: 2 = three persistent workgroups; 16 + g = tile order with GROUP_M = g (17 = column-fastest)
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end, MFMA passes per product)
@@ -374,6 +375,8 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         # this configuration cannot emit them - split-K, activations, unaligned rows: the GroupNorm then runs its own pass)
         p.tile_hint, p.split_k = tile_hint, split_k
         rows = lib.geo4d_conv_gemm_colsum_rows(C.byref(p)) if (tile_hint >= 21 or int(GN_FUSED_STATS) >= 2) else 0
+        if split_k > 1 and not SPLITK_COLSUM:      # (A/B switch: round 6 lets a split-K launch's reduce kernel emit the sums)
+            rows = 0
         if rows == 0 and int(GN_FUSED_STATS) >= 2:
             # mode 2 (A/B, tests): a tuned configuration that cannot emit the sums (split-K; a second / third generation tile on 16-bit rows)
             # gives way to an un-split first-generation launch, as this path did before round 4

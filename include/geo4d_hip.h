@@ -92,14 +92,17 @@ typedef struct geo4d_conv_gemm_t {
     float* gn_colsum;    /* optional [M/rows][N][2] fp32 (rows = geo4d_conv_gemm_colsum_rows(p): 32 for the first generation): per row block and output column, (sum, sum of squares) of the values this
                             launch stores - the statistics pass of the GroupNorm that consumes O, produced for free by the epilogue
                             (geo4d_groupnorm_t.colsum). Needs M % 32 == 0, N % 8 == 0, row-major 16-byte aligned output, batch 1,
-                            no GEGLU and no split-K. */
+                            no GEGLU; no split-K on the first generation. Round 6: a split-K launch of tile hints >= 22 emits them from its
+                            reduce launch, per 32 rows (N % 64 == 0) or, where a frame's Hout x Wout rows are a multiple of 8 but not of 32, per
+                            8 rows (N % 256 == 0): geo4d_conv_gemm_colsum_rows says which. */
     unsigned long long* sat_count; /* optional DEBUG counter in device memory (NULL in production): o_split = 2 launches add the number of
                             (wave, store) lanes whose value lay beyond the finite f16 range and was clamped. Tests assert it stays 0. */
 } geo4d_conv_gemm_t;
 int geo4d_conv_gemm(const geo4d_conv_gemm_t* p, void* stream);
 /* Rows of the output that ONE gn_colsum entry of the launch `*p` describes covers (tile_hint / split_k as they will be launched, the
-   gn_colsum field itself ignored): 32 for the first-generation tiles, the wave tile's rows (32..128) for tile hints >= 21; 0 = this
-   launch cannot emit the sums. gn_colsum then has [M / rows][N][2] floats. */
+   gn_colsum field itself ignored): 32 for the first-generation tiles, the wave tile's rows (32..128) for tile hints >= 21 without split-K,
+   32 or 8 for their split-K launches (the reduce launch sums them); 0 = this launch cannot emit the sums. gn_colsum then has
+   [M / rows][N][2] floats. */
 int geo4d_conv_gemm_colsum_rows(const geo4d_conv_gemm_t* p);
 
 /* GroupNorm(groups) [+SiLU] over tokens [F][HW][C]; statistics per (F / frames_per_stat, group) in fp32.

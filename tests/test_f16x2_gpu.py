@@ -314,3 +314,29 @@ def test_geglu_feed_forward_chain_two_pass(dev, tile):
     for bad in (23, 72, 73):
         with pytest.raises(RuntimeError):
             ops.linear(xs, wp, bp, act=2, split_out="f16", tile_hint=bad, split_k=1)
+
+
+@pytest.mark.parametrize("H,W,rows", [(10, 16, 32), (5, 8, 8)])
+def test_split_k_launch_emits_groupnorm_sums_from_its_reduce(dev, H, W, rows):
+    """Round 6: a split-K launch of the second / third generation emits the consumer GroupNorm's column sums from its reduce launch
+    (splitk_reduce_colsum_kernel: per 32 rows, or per 8 where a frame has 40 rows - the 5 x 8 level), so the GroupNorms behind the level-2 / 3
+    convolutions skip their statistics pass like the others. The conv output is bit-identical to the plain reduce kernel's; the GroupNorm from
+    the sums equals the one that makes its own pass to fp32 round-off (per-frame and 5-D statistics)."""
+    from geo4d_amd import ops, pack
+    F, C = 16, 1280
+    xt = rnd((F * H * W, C), dev, 100).to(torch.float16).contiguous()
+    wp, bc = pack.pack_conv2d_x2(rnd((C, C, 3, 3), dev, 101, 0.01), "bf16x3m"), rnd((C,), dev, 102)
+    emb, r = rnd((1, C), dev, 103), rnd((F * H * W, C), dev, 104)
+    gamma, beta = rnd((C,), dev, 105) + 1.0, rnd((C,), dev, 106)
+    for tile in (23, 72, 73):
+        run = lambda gs: ops.conv2d(xt, wp, bc, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, rowbias=emb, rowbias_div=F * H * W, residual=r, tile_hint=tile,
+                                    split_k=4, gn_stats=gs)[0]
+        plain, h = run(False), run(True)
+        assert torch.equal(h, plain), f"tile {tile}"
+        assert getattr(h, "_gn_colsum", None) is not None and h._gn_colsum_rows == rows and tuple(h._gn_colsum.shape) == (F * H * W // rows, C, 2)
+        want = plain.double().reshape(-1, rows, C)
+        assert rel(h._gn_colsum[:, :, 0], want.sum(1)) < 1e-5 and rel(h._gn_colsum[:, :, 1], (want * want).sum(1)) < 1e-5
+        for fps in (1, 16):
+            a = ops.groupnorm(h, gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True, split_out="f16")
+            b = ops.groupnorm(plain.clone(), gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True, split_out="f16")
+            assert rel(a.float(), b.float()) < 1e-4 and float((a.float() - b.float()).abs().max()) < 0.02       # (f16 outputs: an ulp here and there)

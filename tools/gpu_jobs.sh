@@ -178,6 +178,24 @@ PY
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -4 $O/smoke.log
     fi
     ;;
+  r6h)         # split-K reduce emitting the GroupNorm column sums: tests, A/B by environment switch
+    ( time timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_gemm_v2_gpu.py tests/test_gemm_v3_gpu.py tests/test_kernels_gpu.py -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest.log | tail -8
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -4 $O/smoke.log
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "frac", round(r["frac"], 4), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for i in 1 2; do
+      GEO4D_SPLITK_COLSUM=0 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows > $O/bench_off_$i.json 2> $O/bench_off_$i.err; bl $O/bench_off_$i.json "split-K colsum off run $i:"
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows > $O/bench_on_$i.json 2> $O/bench_on_$i.err; bl $O/bench_on_$i.json "split-K colsum on run $i:"
+    done
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
