@@ -338,7 +338,7 @@ def test_sharded_residual_kernel_sums_to_the_full_objective(fix, dev):
     n = full.n
     parts = []
     for r in range(2):
-        sh = AlignShard(fix["groups"], n, rank=r, world=2)
+        sh = AlignShard(fix["groups"], n, rank=r, world=2, exchange="allreduce")     # (the packed all-reduce form: one buffer per rank to add by hand)
         sh._all_reduce = lambda t: t                         # no process group here: ranks are summed by hand below
         a = _late_aligner(fix, dev, "after", shard=sh)
         a.set_state(d["invalid_depth_groups"], d["valid_traj_groups"])
@@ -361,7 +361,7 @@ def test_sharded_residual_kernel_sums_to_the_full_objective(fix, dev):
     ref.start_depth_traj()
     tabs = []
     for r in range(2):
-        sh = AlignShard(fix["groups"], n, rank=r, world=2)
+        sh = AlignShard(fix["groups"], n, rank=r, world=2, exchange="allreduce")
         sh._all_reduce = lambda t: t
         sh.merge_rows = (lambda table, rows, _sh=sh: table * torch.zeros(table.shape[0], 1, device=table.device).index_fill_(0, torch.tensor(list(rows), device=table.device), 1.0))
         a = _late_aligner(fix, dev, su["at_start"], shard=sh)

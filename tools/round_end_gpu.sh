@@ -30,7 +30,7 @@ for n in ("ab_r5_1", "ab_r6_1", "ab_r5_2", "ab_r6_2"):
 PY
 fi
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --dtype $MODE --no-cpu-baseline --no-fast-mode --no-strict-mode --no-shipped-setting --no-clip-leg > $O/kt.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --dtype $MODE --no-cpu-baseline --no-fast-mode --no-strict-mode --no-shipped-setting --no-clip-leg --no-batched-windows > $O/kt.log 2>&1
 find /tmp/prof/kt -name "*kernel_stats.csv" -exec cp {} $O/kt_kernel_stats.csv \;
 KT=$(find /tmp/prof/kt -name "*kernel_trace.csv" | head -1)
 [ -n "$KT" ] && python $R/tools/prof_phases.py $KT 30 > $O/phases.md 2>&1
