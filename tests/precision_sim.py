@@ -80,6 +80,9 @@ class S_:
         w = self.w(p + ".weight")
         if cls is not None and "v1" in cls and "wv16" in self.sc.two_pass:      # round 6: the V^T projection as ONE f16 pass (weight rounded to f16 too)
             w = self.sd[p + ".weight"].to(torch.float16).float()
+        w16 = getattr(self.sc, "w16", ())            # classes whose WEIGHTS are ONE f16 as well (a single-pass f16 GEMM)
+        if cls is not None and any(c in w16 for c in ((cls,) if isinstance(cls, str) else cls)):
+            w = self.sd[p + ".weight"].to(torch.float16).float()
         return F.linear(x, w.reshape(w.shape[0], -1), self.sd.get(p + ".bias") if bias else None)
 
     def gn(self, x, p, eps):
@@ -101,7 +104,8 @@ class S_:
     def conv3(self, x, p):
         if "tconv" in self.sc.two_pass:
             x = x.to(torch.float16).float()
-        return F.conv3d(x, self.w(p + ".weight"), self.sd[p + ".bias"], padding=(1, 0, 0))
+        w = self.sd[p + ".weight"].to(torch.float16).float() if "tconv" in getattr(self.sc, "w16", ()) else self.w(p + ".weight")
+        return F.conv3d(x, w, self.sd[p + ".bias"], padding=(1, 0, 0))
 
 
 def _mha(sc, q, k, v, heads, self1=False, tself_f16=False, cross=False):
@@ -356,6 +360,14 @@ SCHEMES += [
     _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6 + ("attn_out_t",), attn1="f16", name="R6 default + temporal attention chain (tattn)"), attnT="f16"),
     _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6 + ("attn_out_c",), attn1="f16", name="R6 default + cross-attention chain (q, K, V, P one f16; two-pass to_out) (cattn)"), attnC="f16"),
     _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6 + ("attn_out_c", "attn_out_t"), attn1="f16", name="R6 default + tattn + cattn"), attnC="f16", attnT="f16"),
+]
+M6D = M6 + ("attn_out_t", "attn_out_c")
+SCHEMES += [
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6D, attn1="f16", name="R6 HEAD default (attn + cattn + tattn)"), attnC="f16", attnT="f16"),
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6D, attn1="f16", name="R6 HEAD + ff weights ONE f16 (single-pass GEGLU / ff-out)"), attnC="f16", attnT="f16", w16=("ff",)),
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6D, attn1="f16", name="R6 HEAD + tconv weights ONE f16"), attnC="f16", attnT="f16", w16=("tconv",)),
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16x2", vae3=True, two_pass=M6D, attn1="f16", name="R6 HEAD + ln / qk1 / attn_out weights ONE f16 (all attention projections single-pass)"), attnC="f16", attnT="f16", w16=("ln", "qk1", "attn_out")),
+    _with(Scheme("bf16x2", "bf16x2", "f32", c3a="f16", c3w="f16", vae3=False, two_pass=M6D, attn1="f16", name="R6 HEAD + U-Net conv3x3 weights ONE f16 (VAE stays two-pass)"), attnC="f16", attnT="f16"),
 ]
 if os.environ.get("SIM_ONLY"):
     SCHEMES = [sc for sc in SCHEMES if any(k in sc.name for k in os.environ["SIM_ONLY"].split(","))]
