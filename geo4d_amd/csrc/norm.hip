@@ -9,6 +9,7 @@
 // Statistics are always fp32 (partials merged with Chan's formula in fp64), activations are read and written
 // as 16-byte chunks (8 x bf16/f16 or 4 x f32 per lane) — cdna_hip_programming.md G13.
 // All reductions are order-deterministic (no atomics): the same input gives bit-identical output.
+#include <type_traits>
 #include "common.h"
 #include "geo4d_hip.h"
 
@@ -302,6 +303,57 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
     }
 }
 
+// ---- LayerNorm, 16 lanes per row (round 6): the widths of U-Net levels 0 / 1 (320 / 640 f32 channels = 80 / 160 16-byte chunks) are
+// multiples of 16 chunks but not of 64: the one-wave-per-row kernel above leaves 3/8 of its lanes idle at C = 320 (80 chunks on 64 lanes: two passes,
+// the second with 16 lanes). Here a wave owns FOUR rows, a quarter-wave each: lane (row = lane >> 4, l = lane & 15) holds chunks l, l + 16, ... of its
+// row (every load instruction of a quarter-wave = 256 contiguous bytes), statistics by a fixed DPP tree inside the 16 lanes. f32 input only (the
+// storage type of the modes that use it); same outputs as ln_kernel up to the summation order of the statistics.
+__device__ __forceinline__ float quarter_sum(float v) {      // sum over the 16 lanes of a DPP row, every lane gets the total
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));     // row_mirror
+    return v;
+}
+template <int NCH, int SPLIT>        // NCH = chunks per lane (C = 64 NCH); SPLIT as ln_kernel
+__global__ __launch_bounds__(256) void ln16_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, int M,
+                                                   float eps, const float* __restrict__ gamma, const float* __restrict__ beta, unsigned long long* sat) {
+    constexpr int C = 64 * NCH;
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool ok = row < M;
+    const float* xr = x + (ok ? row : 0) * ldx;
+    float e[NCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const u32x4 v = *(const u32x4*)(xr + (l + 16 * i) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e[i][j] = __uint_as_float(v[j]); s += e[i][j]; }
+    }
+    const float mean = quarter_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = e[i][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(quarter_sum(q) / (float)C + eps);
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int cc = l + 16 * i;
+        const f32x4 g = *(const f32x4*)(gamma + cc * 4), b = *(const f32x4*)(beta + cc * 4);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (e[i][j] - mean) * rstd * g[j] + b[j];
+        if constexpr (SPLIT == 1) store_split4(y + row * ldy, cc, o);
+        else if constexpr (SPLIT == 2) {
+            count_f16_saturation(sat, o);
+            store4_f16((char*)y + row * ldy * 2, cc, o);
+        } else *(f32x4*)(y + row * ldy + cc * 4) = f32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+
 // ---- row softmax: y = softmax(scale * x), x fp32, one workgroup per row --------------------
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
@@ -362,6 +414,17 @@ template <typename T, int SPLIT = 0>
 int layernorm_typed(const void* x, long ldx, void* y, long ldy, int M, int C, float eps, const float* g, const float* b,
                     hipStream_t s, unsigned long long* sat = nullptr) {
     constexpr int EPC = Elem<T>::EPC;
+    if constexpr (std::is_same<T, float>::value) {
+        // f32 rows whose width is a multiple of 64 channels (every width of the U-Net): four rows per wave, no idle lanes
+        const bool al = ((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0;
+        const dim3 grid16((M + 15) / 16);
+#define LN16_LAUNCH(NC) hipLaunchKernelGGL((ln16_kernel<NC, SPLIT>), grid16, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, M, eps, g, b, sat)
+        // measured in the HEAD trace (us per launch, one-wave-per-row -> this kernel): C = 320 at M = 40960 20.4 -> 15.1, C = 640 at M = 10240 11.8 -> 10.6;
+        // C = 1280 at M = 2560 7.8 -> 12.7 (160 workgroups of long per-lane chains: it stays on ln_kernel, as does C = 512 = exactly 2 chunks per lane there)
+        if (al && C == 320) { LN16_LAUNCH(5); GEO4D_CHECK_LAUNCH(); return GEO4D_OK; }
+        if (al && C == 640) { LN16_LAUNCH(10); GEO4D_CHECK_LAUNCH(); return GEO4D_OK; }
+#undef LN16_LAUNCH
+    }
     const int per_lane = (C / EPC + 63) / 64;
     const dim3 grid((M + 3) / 4);
 #define LN_LAUNCH(MC) hipLaunchKernelGGL((ln_kernel<T, MC, SPLIT>), grid, dim3(256), 0, s, (const T*)x, ldx, (T*)y, ldy, M, C, eps, g, b, sat)
