@@ -276,10 +276,9 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         _split_out_ok(out, M)
     a_split, w_split = is_split(a, w), is_split(w, a)
     assert not is_x2_weight(a), "a pack.split_f16 weight is the W operand"
-    x2 = is_x2_weight(w)
-    if x2 or (a.dtype == torch.float16 and w.dtype == torch.float16 and isinstance(w, X2Weight)):
+    if isinstance(w, X2Weight):
         # two-pass f16 (dtype 4): plain f16 activation rows (GroupNorm / LayerNorm / GEGLU-epilogue output) x a pack.split_f16 weight (which carries its 1 / scale)
-        assert x2, "a two-pass weight lost its scale (sliced / reshaped X2Weight?)"
+        assert is_x2_weight(w), "a two-pass weight without its scale"
         assert a.dtype == torch.float16 and not isinstance(a, SplitAct), "a pack.split_f16 weight multiplies plain float16 activation rows (the two-pass form has no raw-f32 launch)"
         assert out.dtype in (torch.float16, torch.float32) and not isinstance(out, SplitAct) and not out_nchw, "the two-pass f16 GEMM writes plain f32 rows or plain f16 rows"
         assert ldw % 2 == 0 and w_bs % 2 == 0

@@ -7,12 +7,14 @@ name       activation storage   GEMM / attention arithmetic   point-map parity v
 ``f16``    float16              f16 MFMA, fp32 accumulate     ~2.5e-3
 ``bf16x3`` float32              3 bf16 MFMAs per product on   < 1e-4: meets the bar at ~1/3 of the bf16 MFMA rate
                                 a hi/lo split of each operand
-``bf16x3m`` float32             bf16x3, except the long-K     ~2e-4 (measured at BASELINE size over 50 steps:
-                                3x3 convolutions (U-Net       tests/test_fullsize_gpu.py): the convolutions that are
-                                ResBlocks, VAE ResnetBlocks): MFMA-bound issue 2 MFMAs per product instead of 3
-                                two f16 MFMAs per product on
-                                an f16 activation x an
-                                f16 hi + lo weight
+``bf16x3m`` float32 streams;    bf16x3, except the GEMMs fed  1.8e-4 against the REFERENCE's own 50-step window at
+           f16 rows for         by a normalised branch        BASELINE size (tests/golden/fullsize_ddim50.pt,
+           branch activations   activation (TWO_PASS_CLASSES  tests/test_fullsize_gpu.py); 6.5e-4 on the tiny smoke
+                                below): two f16 MFMAs per     window (its worst case)
+                                product on an f16 activation
+                                x an f16 hi + lo weight; the
+                                three attention kernels: ONE
+                                f16 MFMA per product
 ``f32``    float32              v_mfma_f32_32x32x2_f32        ~2e-6 (exact f32; 1/16 of the bf16 MFMA rate)
 =========  ===================  ============================  ==========================================================
 
