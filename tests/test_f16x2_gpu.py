@@ -340,3 +340,22 @@ def test_split_k_launch_emits_groupnorm_sums_from_its_reduce(dev, H, W, rows):
             a = ops.groupnorm(h, gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True, split_out="f16")
             b = ops.groupnorm(plain.clone(), gamma, beta, F=F, HW=H * W, eps=1e-5, frames_per_stat=fps, silu=True, split_out="f16")
             assert rel(a.float(), b.float()) < 1e-4 and float((a.float() - b.float()).abs().max()) < 0.02       # (f16 outputs: an ulp here and there)
+
+
+def test_cast_rows_f16(dev):
+    """geo4d_cast_rows_f16 (class `vaeup`: an f16 copy of an f32 stream as a two-pass GEMM's A operand): f16(clamp(x)) element for element,
+    pitched input rows, NaN kept, clamped lanes counted."""
+    from geo4d_amd import ops
+    wide = rnd((300, 512), dev, 110) * 100.0
+    x = wide[:, 128:384]                                     # a column view: row pitch 512
+    x[5, 7], x[9, 0], x[11, 3] = 1.0e6, -2.0e6, float("nan")
+    cnt = torch.zeros(1, device=dev, dtype=torch.int64)
+    old = ops.SAT_COUNTER
+    try:
+        ops.SAT_COUNTER = cnt
+        y = ops.cast_f16(x)
+    finally:
+        ops.SAT_COUNTER = old
+    want = x.clamp(-65504.0, 65504.0).to(torch.float16)
+    ok = ~torch.isnan(x)
+    assert y.dtype == torch.float16 and y.shape == x.shape and torch.equal(y[ok], want[ok]) and bool(torch.isnan(y[11, 3])) and int(cnt.item()) == 2
