@@ -71,8 +71,8 @@ extern "C" int geo4d_conv_gemm(const geo4d_conv_gemm_t* pp, void* stream) {
             geo4d_set_error("conv_gemm: f16x2 (dtype 4) needs a_split = 2 (plain f16 activation rows) and w_split, a row-major output (f32 rows, or o_split = 2: plain f16 rows), and tile hint 0 or >= 22");
             return GEO4D_EINVAL;
         }
-        // (GEGLU and the f16-row epilogue live on the tiles whose wave tiles are a multiple of 64 columns wide)
-        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? ((p.act == 2 || p.o_split) ? 71 : 72) : 25;
+        // (GEGLU lives on the tiles whose wave tiles are a multiple of 64 columns wide)
+        if (p.tile_hint == 0) p.tile_hint = p.M >= 4096 ? (p.act == 2 ? 71 : 72) : 25;
         if (p.split_k == 0) p.split_k = 1;
     }
     if (p.o_split) {

@@ -107,7 +107,7 @@ inline bool colsum_fast_ok(const geo4d_conv_gemm_t& p, int sp) {
 // The two-pass f16 type has no 256x256 instantiation (that tile spills a few registers around its K loop, and the long-K convolutions
 // the type exists for run on the phased tiles): hint 22 means the 160x320 tile there - same bits, every tile sums in the same order.
 // (GEGLU needs wave tiles a multiple of 64 columns wide, which 160x320 is not: 128x128 there.)
-template <typename T> inline int v2_effective_hint(int hint, int act = 0, int o_split = 0) { return (IsTwoPass<T>::value && hint == 22) ? ((act == 2 || o_split) ? 25 : 23) : hint; }
+template <typename T> inline int v2_effective_hint(int hint, int act = 0, int o_split = 0) { return (IsTwoPass<T>::value && hint == 22) ? (act == 2 ? 25 : 23) : hint; }
 inline int v2_wave_rows(int hint) { return hint == 22 ? 64 : hint == 23 ? 80 : hint == 25 ? 64 : (hint == 27 || hint == 28) ? 32 : 0; }
 __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes lr of a 16-lane row, fixed order (DPP: xor 1, xor 2, half mirror, mirror)
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
@@ -775,11 +775,10 @@ int launch_v2_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     if constexpr (IsTwoPass<T>::value) {       // f16x2: pre-split x pre-split; plain f32 rows out, or (o_split = 2) the f16 pre-split format
         if (p.a_split != 2 || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes plain f16 activation rows (a_split = 2) and a pre-split f16 weight; o_split 0 or 2 (plain f16 rows out)"); return GEO4D_EINVAL; }
         if (p.o_split) {
-            // (the f16-halves epilogue exists on the GEGLU-capable tiles only: its one user is the GEGLU -> ff-out chain)
-            if constexpr (((BN / WN / 16) % 4) == 0) {
-                if (o_f16_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
-            }
-            geo4d_set_error("conv_gemm: o_split = 2 (plain f16 rows out) needs a GEGLU-capable tile (wave tiles a multiple of 64 columns wide), no split-K / residual / row biases / SiLU / GELU, stored columns % 8 == 0 and 16-byte aligned output rows");
+            // (the f16-row epilogue: every tile for plain rows - q | k, q | k | v, cross-attention q -, the GEGLU form on the tiles whose wave
+            // tiles are a multiple of 64 columns wide: checked at the top of this function)
+            if (o_f16_ok(p, splits)) return launch_v2_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+            geo4d_set_error("conv_gemm: o_split = 2 (plain f16 rows out) needs no split-K / residual / row biases / SiLU / GELU, stored columns % 8 == 0 and 16-byte aligned output rows");
             return GEO4D_EINVAL;
         }
         return launch_v2_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);

@@ -508,10 +508,10 @@ int launch_v3_cfg(const geo4d_conv_gemm_t& p, int splits, hipStream_t stream) {
     if constexpr (IsTwoPass<T>::value) {
         if (p.a_split != 2 || !p.w_split || (p.o_split && p.o_split != 2)) { geo4d_set_error("conv_gemm: f16x2 (dtype 4) takes plain f16 activation rows (a_split = 2) and a pre-split f16 weight; o_split 0 or 2 (plain f16 rows out)"); return GEO4D_EINVAL; }
         if (p.o_split) {
-            if constexpr (((BN / WN / 16) % 4) == 0) {
-                if (o_f16_ok(p, splits)) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
-            }
-            geo4d_set_error("conv_gemm: o_split = 2 (plain f16 rows out) needs a GEGLU-capable tile (wave tiles a multiple of 64 columns wide), no split-K / residual / row biases / SiLU / GELU, stored columns % 8 == 0 and 16-byte aligned output rows");
+            // (the f16-row epilogue: every tile for plain rows - q | k, q | k | v, cross-attention q -, the GEGLU form on the tiles whose wave
+            // tiles are a multiple of 64 columns wide: checked at the top of this function)
+            if (o_f16_ok(p, splits)) return launch_v3_kernel<T, BM, BN, WM, WN, 2, true>(p, splits, stream);
+            geo4d_set_error("conv_gemm: o_split = 2 (plain f16 rows out) needs no split-K / residual / row biases / SiLU / GELU, stored columns % 8 == 0 and 16-byte aligned output rows");
             return GEO4D_EINVAL;
         }
         return launch_v3_kernel<T, BM, BN, WM, WN, 2>(p, splits, stream);

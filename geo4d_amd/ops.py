@@ -365,9 +365,11 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
             cfg = _autotune(launch, key)
         tile_hint, split_k = cfg if cfg is not None else (0, 0)
         if p.o_split == 2:
-            # the f16-row epilogue lives on the tiles whose wave tiles are a multiple of 64 columns wide (25, 27, 71, 74): a tile borrowed from
-            # the bf16x3 entry of the same shape goes to its nearest such neighbour, and there is no split-K
-            tile_hint, split_k = {22: 25, 23: 25, 28: 27, 72: 71, 73: 74}.get(tile_hint, tile_hint), min(split_k, 1)
+            # the f16-row epilogue has no split-K; its GEGLU form lives on the tiles whose wave tiles are a multiple of 64 columns wide
+            # (25, 27, 71, 74): a tile borrowed from the bf16x3 entry of the same shape goes to its nearest such neighbour
+            split_k = min(split_k, 1)
+            if act == 2:
+                tile_hint = {22: 25, 23: 25, 28: 27, 72: 71, 73: 74}.get(tile_hint, tile_hint)
     if gn_stats and GN_FUSED_STATS and not p.o_split and batch == 1 and out.dim() == 2 and out.shape[0] == M:
         # the consumer GroupNorm's statistics pass, for free: per row block and column (sum, sum of squares) from the epilogue. The library
         # says how many rows one entry of THIS launch covers (32 for the first generation, the wave tile's rows for the second / third; 0 =

@@ -196,6 +196,31 @@ PY
       timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows > $O/bench_on_$i.json 2> $O/bench_on_$i.err; bl $O/bench_on_$i.json "split-K colsum on run $i:"
     done
     ;;
+  r6i)         # the f16-row epilogue on every two-pass tile (160x320 for N = 640 / 960 / 1920 ...): tests, re-tune the "o" launches, A/B old vs new table
+    ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py tests/test_gemm_v3_gpu.py -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest.log | tail -6
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "frac", round(r["frac"], 4))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_before.json
+    timeout 1200 python tools/tune_gemm.py $O/gfx950.json --keep --drop-suffix=x11o --batch=1 --batch=2 bf16x3m > $O/tune.log 2>&1; show $O/tune.log | tail -3
+    grep -c "" $O/gfx950.json.log; grep "x11o" $O/gfx950.json.log | cut -c1-230 | head -40
+    if [ -s $O/gfx950.json ]; then
+      for i in 1 2; do
+        cp $O/gfx950_before.json geo4d_amd/tuning/gfx950.json
+        timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows --no-shipped-setting > $O/bench_old_$i.json 2> $O/bench_old_$i.err; bl $O/bench_old_$i.json "old table run $i:"
+        cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+        timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows --no-shipped-setting > $O/bench_new_$i.json 2> $O/bench_new_$i.err; bl $O/bench_new_$i.json "new table run $i:"
+      done
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke
+    fi
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12

@@ -19,8 +19,12 @@ def main():
     old = dict(ops._tune_table())
     keep = "--keep" in sys.argv          # --keep: only shapes MISSING from the table are measured (a new mode's launches), the rest keep their entry
     drop = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--drop-prefix=")]      # with --keep: forget the entries whose key starts with this (e.g. 4/ = the two-pass f16 launches) so that they are re-measured
+    for suf in [a.split("=", 1)[1] for a in sys.argv if a.startswith("--drop-suffix=")]:      # e.g. --drop-suffix=x11o: the f16-row-output launches
+        for k in [k for k in ops._tune_table() if k.endswith(suf)]:
+            del ops._tune_table()[k]
+            old.pop(k, None)
     batches = [int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--batch=")] or [1]      # --batch=2: the shapes of two windows per step (run_clip window_batch)
-    sys.argv = [a for a in sys.argv if not a.startswith("--drop-prefix=") and not a.startswith("--batch=")]
+    sys.argv = [a for a in sys.argv if not a.startswith("--drop-prefix=") and not a.startswith("--batch=") and not a.startswith("--drop-suffix=")]
     for pre in drop:
         for k in [k for k in ops._tune_table() if k.startswith(pre)]:
             del ops._tune_table()[k]
