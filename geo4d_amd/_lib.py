@@ -117,6 +117,7 @@ SIGNATURES = {
     "geo4d_tokens_from_ncthw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_void_p]),
     "geo4d_cast_rows_f16": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "geo4d_split_rows_bf16": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p]),
     "geo4d_concat_channels": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long,
                                         C.c_long, C.c_int, C.c_void_p]),
     "geo4d_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -58,6 +58,20 @@ __global__ __launch_bounds__(256) void cast_rows_f16_kernel(const float* __restr
     }
 }
 
+// f32 rows -> the bf16x3 PRE-SPLIT operand format ([8 x bf16 hi | 8 x bf16 lo] per 8 elements: what conv_gemm's in-register split computes per
+// fragment, done once): 8 elements per lane, two 16-byte loads, two 16-byte stores
+__global__ __launch_bounds__(256) void split_rows_bf16_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long M, int c8) {
+    const long total = M * c8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / c8;
+        const int g = (int)(idx - m * c8);
+        const u32x4 a = *(const u32x4*)(x + m * ldx + g * 8), b = *(const u32x4*)(x + m * ldx + g * 8 + 4);
+        const float e[8] = {__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3]),
+                            __uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+        store_split8(y + m * ldy, g, e);
+    }
+}
+
 __global__ void timestep_embedding_kernel(const long* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out,
                                           int B, int half) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,6 +171,19 @@ extern "C" int geo4d_cast_rows_f16(const float* x, long ldx, void* y, long ldy, 
     long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(cast_rows_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)y, ldy, M, C / 8, sat_count);
+    GEO4D_CHECK_LAUNCH();
+    return GEO4D_OK;
+}
+
+extern "C" int geo4d_split_rows_bf16(const float* x, long ldx, void* y, long ldy, long M, int C, void* stream) {
+    if (M <= 0 || C <= 0 || (C % 8) || (ldx % 4) || (ldy % 8) || ((uintptr_t)x % 16) || ((uintptr_t)y % 32)) {
+        geo4d_set_error("split_rows_bf16: C % 8 == 0, 16-byte aligned input rows, 32-byte aligned output rows");
+        return GEO4D_EINVAL;
+    }
+    const long total = M * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(split_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (float*)y, ldy, M, C / 8);
     GEO4D_CHECK_LAUNCH();
     return GEO4D_OK;
 }

@@ -187,7 +187,8 @@ def _env_level(name, default):
 
 
 GN_FUSED_STATS = _env_level("GEO4D_GN_FUSED", 1)
-SPLITK_COLSUM = _env_level("GEO4D_SPLITK_COLSUM", 1)       # 0: split-K launches leave the GroupNorm statistics to the GroupNorm (the state before round 6)
+SPLITK_COLSUM = _env_level("GEO4D_SPLITK_COLSUM", 1)
+TUNE_EXACT = _env_level("GEO4D_TUNE_EXACT", 0)     # tools/tune_gemm.py: measure a pre-split launch under its OWN key instead of borrowing the raw-activation entry of the same shape       # 0: split-K launches leave the GroupNorm statistics to the GroupNorm (the state before round 6)
 TUNE_LOG = []          # (key, chosen (tile, split), ms per launch, finalists) of every shape autotuned in this process (tools/tune_gemm.py prints it)
 DEBUG_ABLATE = _env_level("GEO4D_DEBUG_ABLATE", 0)       # tests / A-B runs: 2 = three persistent workgroups; 16 + g = tile order with GROUP_M = g (17 = column-fastest)
 GEMM_TIMELINE = None   # set to a list to have conv_gemm bracket every launch with HIP events: (flops, start, end, MFMA passes per product)
@@ -346,7 +347,7 @@ def conv_gemm(a, w, out, *, M, N, K, Cin, lda, ldw, ldo, T=1, Hin=1, Win=1, Hout
         if code in (BF16X3, F16X2):
             key += f"|x{int(bool(a_split))}{int(w_split)}" + ("o" if p.o_split else "")       # (dtype 4's "o" = its f16 rows)
         cfg = _tune_table().get(key)
-        if cfg is None and code == BF16X3 and a_split and w_split:
+        if cfg is None and code == BF16X3 and a_split and w_split and not (TUNE_EXACT and AUTOTUNE and not torch.cuda.is_current_stream_capturing()):
             # pre-split activations: same tile geometry as the raw-activation launch of the same shape (table measured on those)
             base = key.split("|x")[0]
             cfg = (_tune_table().get(base + "|x11") if p.o_split else None) or _tune_table().get(base + "|x01") or _tune_table().get(base + "|x10")
@@ -695,6 +696,18 @@ def cast_f16(x, out=None):
     if out is None:
         out = torch.empty((M, Cc), device=x.device, dtype=torch.float16)
     _lib.check(lib.geo4d_cast_rows_f16(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), M, Cc, _ptr(SAT_COUNTER), _stream()), "geo4d_cast_rows_f16")
+    return out
+
+
+def presplit(x):
+    """f32 rows [M, C] -> SplitAct (the bf16x3 pre-split operand format): conv_gemm then skips its in-register split of the A fragments (12-29 %
+    of a launch, paid per K slab and wave). Worth its own pass only where every input element is used many times: the 3x3 Upsample convolutions."""
+    lib = _lib.load()
+    _dev(x, "x")
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 8 == 0
+    M, Cc = x.shape
+    out = new_split(M, Cc, x.device)
+    _lib.check(lib.geo4d_split_rows_bf16(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out) // 2, M, Cc, _stream()), "geo4d_split_rows_bf16")
     return out
 
 

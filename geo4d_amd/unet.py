@@ -165,6 +165,7 @@ def layer_shapes(add, L, c):
 
 
 PRESPLIT = os.environ.get("GEO4D_X3_PRESPLIT", "1") != "0"
+PRESPLIT_UP = os.environ.get("GEO4D_X3_PRESPLIT_UP", "1") != "0"      # A/B switch of round 6: pre-split pass in front of the Upsample convolutions (U-Net and VAE)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -543,7 +544,9 @@ class UNetModel(ParamTree):
             elif L.kind == "down":
                 h, H, W = ops.conv2d(h, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, stride=2, pad=1, gn_stats=True)
             elif L.kind == "up":
-                h, H, W = ops.conv2d(h, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2)
+                # (bf16x3 modes: the stream is split ONCE by its own pass instead of per K slab and wave inside the conv - same bits, PRESPLIT_UP)
+                a = ops.presplit(h) if (self.presplit and PRESPLIT_UP) else h
+                h, H, W = ops.conv2d(a, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2)
         return h, H, W
 
     # ---- public forward -------------------------------------------------------------------------------------

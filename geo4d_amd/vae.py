@@ -298,7 +298,8 @@ class AutoencoderKL(ParamTree):
             elif kind == "attn":
                 x = self._attn(P[p], x, n, H, W)
             else:
-                a = ops.cast_f16(x) if ops.is_x2_weight(P[p][0]) else x
+                from .unet import PRESPLIT_UP
+                a = ops.cast_f16(x) if ops.is_x2_weight(P[p][0]) else ops.presplit(x) if (self.presplit and PRESPLIT_UP) else x
                 x, H, W = ops.conv2d(a, *P[p], F=n, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2, gn_stats=True)
         return x, H, W
 

@@ -197,6 +197,11 @@ int geo4d_concat_channels(const void* a, long lda, int Ca, const void* b, long l
  * "vaeup". Values clamped to the finite f16 range, NaN kept; `sat_count` = optional debug counter of the clamp (NULL in production). C % 8 == 0. */
 int geo4d_cast_rows_f16(const float* x, long ldx, void* y, long ldy, long M, int C, unsigned long long* sat_count, void* stream);
 
+/* y = x in the PRE-SPLIT bf16x3 operand format (geo4d_conv_gemm_t.a_split = 1: per 8 elements [8 x bf16 hi | 8 x bf16 lo]; ldy counts 4-byte units like
+ * ldx): what the GEMM's in-register split computes per fragment and K slab, done ONCE - for the long-K launches whose A operand is a residual stream
+ * (the Upsample convolutions of the U-Net and of the VAE decoder: every input element is gathered 9 x 4 times). Same arithmetic, same bits. C % 8 == 0. */
+int geo4d_split_rows_bf16(const float* x, long ldx, void* y, long ldy, long M, int C, void* stream);
+
 /* out[b] = [cos(t_b * f) | sin(t_b * f)]; replaces timestep_embedding (utils_diffusion.py:8-28). */
 int geo4d_timestep_embedding(const long* t, const float* freqs, float* out, int B, int dim, void* stream);
 

@@ -238,3 +238,22 @@ def test_spatial_attention_on_presplit_qkv_equals_raw(dev):
         v = vt.reshape(F, H, 64, npad)[..., :N].permute(0, 1, 3, 2)
         ref = TF.scaled_dot_product_attention(q.double(), k.double(), v.double()).permute(0, 2, 1, 3).reshape(F * N, C).float()
         assert ((raw - ref).norm() / ref.norm()).item() < 3e-5
+
+
+def test_presplit_pass_in_front_of_an_upsample_conv_is_bit_identical(dev):
+    """Round 6: ops.presplit (geo4d_split_rows_bf16) turns an f32 stream into the pre-split operand ONCE; the nearest-2x Upsample convolution
+    that consumes it (second generation: the gather handles the upsampling) then skips its in-register split - the same arithmetic, so the
+    same bits as the raw-activation launch of the same tile; pitched input rows."""
+    from geo4d_amd import ops, pack
+    from test_gemm_v2_gpu import rnd
+    F, H, W, C = 3, 10, 16, 256
+    wide = rnd((F * H * W, 2 * C), dev, 7)
+    x = wide[:, C:]                                          # row pitch 2C
+    w, b = pack.pack_conv2d(rnd((192, C, 3, 3), dev, 8, 0.03), "bf16x3"), rnd((192,), dev, 9)
+    xs = ops.presplit(x)
+    assert isinstance(xs, ops.SplitAct) and xs.dtype == torch.bfloat16 and tuple(xs.shape) == (F * H * W, 2 * C)
+    assert torch.equal(xs.as_subclass(torch.Tensor), pack.split_bf16(x.contiguous()))
+    for tile in (22, 23, 25):
+        raw = ops.conv2d(x, w, b, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2, tile_hint=tile, split_k=1)[0]
+        pre = ops.conv2d(xs, w, b, F=F, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2, tile_hint=tile, split_k=1)[0]
+        assert raw.shape == (F * 4 * H * W, 192) and torch.equal(pre, raw), f"tile {tile}"

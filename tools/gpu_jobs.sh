@@ -221,6 +221,46 @@ PY
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke
     fi
     ;;
+  r6j)         # pre-split pass in front of the Upsample convolutions (U-Net + VAE): bit-identical? faster? (A/B by environment switch)
+    ( time timeout 600 python -m pytest tests/test_presplit_gpu.py tests/test_f16x2_gpu.py -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest.log | tail -6
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "frac", round(r["frac"], 4), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for i in 1 2; do
+      GEO4D_X3_PRESPLIT_UP=0 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows > $O/bench_off_$i.json 2> $O/bench_off_$i.err; bl $O/bench_off_$i.json "presplit-up off run $i:"
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows > $O/bench_on_$i.json 2> $O/bench_on_$i.err; bl $O/bench_on_$i.json "presplit-up on run $i:"
+    done
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke
+    ;;
+  r6k)         # own table entries for the pre-split bf16x3 launches that borrowed the raw-activation entry (incl. the pre-split Upsample convs); A/B
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2), "frac", round(r["frac"], 4), "shipped", round(d.get("shipped_setting", {}).get("value", 0), 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    cp geo4d_amd/tuning/gfx950.json $O/gfx950_before.json
+    timeout 1500 python tools/tune_gemm.py $O/gfx950.json --keep --exact --batch=1 --batch=2 bf16x3m > $O/tune.log 2>&1; show $O/tune.log | tail -3
+    grep -c "" $O/gfx950.json.log; cut -c1-200 $O/gfx950.json.log | head -50
+    if [ -s $O/gfx950.json ]; then
+      for i in 1 2; do
+        cp $O/gfx950_before.json geo4d_amd/tuning/gfx950.json
+        timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows > $O/bench_old_$i.json 2> $O/bench_old_$i.err; bl $O/bench_old_$i.json "old table run $i:"
+        cp $O/gfx950.json geo4d_amd/tuning/gfx950.json
+        timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows > $O/bench_new_$i.json 2> $O/bench_new_$i.err; bl $O/bench_new_$i.json "new table run $i:"
+      done
+    fi
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12

@@ -29,6 +29,9 @@ def main():
         for k in [k for k in ops._tune_table() if k.startswith(pre)]:
             del ops._tune_table()[k]
             old.pop(k, None)
+    if "--exact" in sys.argv:            # pre-split launches get their own entries (ops.TUNE_EXACT) instead of borrowing the raw-activation one
+        sys.argv.remove("--exact")
+        ops.TUNE_EXACT = 1
     if keep:
         sys.argv.remove("--keep")
     else:
