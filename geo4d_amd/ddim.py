@@ -8,6 +8,8 @@ table indexed by a device-side step counter] + [counter -= 1]; nothing in it dep
 captured ONCE into a hipGraph and replayed S times (``use_graph=True``, default when eta == 0; with classifier-free
 guidance the 2 (or 3, ``multicond``) U-Net evaluations and their combination are part of the captured step).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -30,11 +32,15 @@ def make_ddim_timesteps(method, num_ddim, num_ddpm):
 class DDIMSampler(object):
     multicond = False     # True in geo4d_amd.ddim_multiplecond.DDIMSampler (3-way guidance)
 
-    def __init__(self, model, schedule="linear", use_graph=True, **kwargs):
+    def __init__(self, model, schedule="linear", use_graph=True, batch_cfg=None, **kwargs):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.use_graph = use_graph
+        # classifier-free guidance: the 2 (3) U-Net evaluations of a step as ONE forward of batch 2B (3B) - the evaluations are independent, and at
+        # batch B the U-Net's levels 1-3 cannot fill the chip (round 6: two windows per step take 1.64x the time of one, profiles/r06_window_batch.md;
+        # the same holds for two conditionings of one window). GEO4D_CFG_BATCH=0 / batch_cfg=False: one forward per conditioning, as before.
+        self.batch_cfg = (os.environ.get("GEO4D_CFG_BATCH", "1") != "0") if batch_cfg is None else bool(batch_cfg)
         self._static = None       # captured step + its static buffers (state, step counter, copies of the conditioning)
         self._graph_key = None
 
@@ -102,6 +108,17 @@ class DDIMSampler(object):
             else:
                 v.copy_(src[k])
 
+    @staticmethod
+    def _fill_cat(cat, parts, fs):
+        """Refresh the batched conditioning buffers IN PLACE from the per-conditioning static copies (a captured step keeps their pointers)."""
+        B = next(iter(parts[0].values()))[0].shape[0]
+        for k, v in cat["cond"].items():
+            for j, dst in enumerate(v):
+                for r, c in enumerate(parts):
+                    dst[r * B:(r + 1) * B].copy_(c[k][j])
+        if cat["fs"] is not None and fs is not None:
+            cat["fs"].copy_(fs.repeat(len(parts)))
+
     def _prepare(self, conds, T):
         """Project / refresh the cross-attention K/V of every conditioning OUTSIDE the captured step and return the model's
         validity token (weights generation + K/V buffer identity). Models without the hook (stubs) return None."""
@@ -160,7 +177,9 @@ class DDIMSampler(object):
                 self._copy_cond(st["uc_img"], uc_img)
             if fs is not None:
                 st["fs"].copy_(fs)
-            if self._prepare([st["cond"], st["uc"], st["uc_img"]], T_frames) != st["token"]:
+            if st.get("cat") is not None:
+                self._fill_cat(st["cat"], [c for c in (st["cond"], st["uc"], st["uc_img"]) if c is not None], st["fs"])
+            if self._prepare([st["cat"]["cond"]] if st.get("cat") is not None else [st["cond"], st["uc"], st["uc_img"]], T_frames) != st["token"]:
                 st = None                      # weights re-packed / K/V buffers replaced since the capture: capture again
         if st is None:
             own = graph_ok                       # eager runs use the caller's tensors directly
@@ -173,8 +192,15 @@ class DDIMSampler(object):
                   "uc_img": (self._clone_cond(uc_img) if own else uc_img) if cfg else None,
                   "fs": None if fs is None else (fs.detach().clone() if own else fs)}
             st["pred_x0"] = torch.empty_like(st["img"])
+            st["cat"] = None
+            parts = [c for c in (st["cond"], st["uc"], st["uc_img"]) if c is not None]
+            if cfg and self.batch_cfg and all(isinstance(c, dict) and set(c) == set(parts[0]) for c in parts):
+                st["cat"] = {"cond": {k: [torch.cat([c[k][j] for c in parts], 0) for j in range(len(v))] for k, v in parts[0].items()},
+                             "fs": None if st["fs"] is None else st["fs"].repeat(len(parts)), "n": len(parts)}
         img, ts, idx, pred_x0 = st["img"], st["ts"], st["idx"], st["pred_x0"]
         c_cond, c_uc, c_img, c_fs = st["cond"], st["uc"], st["uc_img"], st["fs"]
+        cat = st.get("cat")
+        prep_list = [cat["cond"]] if cat is not None else [c_cond, c_uc, c_img]
         mkw = dict(kwargs)
         if "unconditional_conditioning_img_nonetext" in mkw and c_img is not None:
             mkw["unconditional_conditioning_img_nonetext"] = c_img   # forwarded (and ignored) like ddim.py:217 does
@@ -185,6 +211,11 @@ class DDIMSampler(object):
         def model_out():
             if not cfg:
                 return self.model.apply_model(img, ts, c_cond, fs=c_fs, **mkw)
+            if cat is not None:        # the evaluations of this step as one batch: rows [0, B) conditional, [B, 2B) unconditional, [2B, 3B) image-only
+                n = cat["n"]
+                e = self.model.apply_model(img.repeat((n,) + (1,) * (img.dim() - 1)), ts.repeat(n), cat["cond"], fs=cat["fs"], **mkw).float().contiguous()
+                return ops.cfg_combine(e[:batch_size], e[batch_size:2 * batch_size], e[2 * batch_size:] if n == 3 else None,
+                                       scale=unconditional_guidance_scale, cfg_img=cfg_img, guidance_rescale=guidance_rescale)
             e_c = self.model.apply_model(img, ts, c_cond, fs=c_fs, **mkw)
             e_u = self.model.apply_model(img, ts, c_uc, fs=c_fs, **mkw)
             e_i = self.model.apply_model(img, ts, c_img, fs=c_fs, **mkw) if c_img is not None else None
@@ -224,7 +255,7 @@ class DDIMSampler(object):
                 g.replay()
                 log(i)
             st["g"] = g
-            st["token"] = self._prepare([c_cond, c_uc, c_img], T_frames)   # K/V already cached: returns the identity the graph baked in
+            st["token"] = self._prepare(prep_list, T_frames)   # K/V already cached: returns the identity the graph baked in
             self._static, self._graph_key = st, key
         else:
             for i in range(total):
