@@ -609,8 +609,13 @@ def main():
         # (tiles < CUs). The headline above stays BASELINE configs[1] - ONE window per step; this leg times the same work `--window-batch` windows
         # at a time, which is how pipeline.run_clip(window_batch=...) runs a multi-window clip (and the clip leg below).
         bsteps = max(1, min(args.steps, 2))
-        bdt, bsplit = run_mode(DDIMSampler(model, use_graph=not args.no_graph), bsteps, 1, nb=args.window_batch)
-        if rank == 0:
+        try:
+            bdt, bsplit = run_mode(DDIMSampler(model, use_graph=not args.no_graph), bsteps, 1, nb=args.window_batch)
+        except Exception as e:       # noqa: BLE001 - an extra leg must not cost the headline (every rank runs the same code: a failure is symmetric)
+            bdt, bsplit = None, None
+            if rank == 0:
+                res["batched_windows"] = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0 and bdt is not None:
             nbw = args.window_batch
             res["batched_windows"] = {"windows_per_step": nbw, "value": T * nbw * bsteps * world / bdt, "unit": "frames/s", "ms_per_step": 1e3 * bdt / bsteps,
                                       "ms_per_window": 1e3 * bdt / bsteps / nbw, "steps": bsteps, "dtype": args.dtype,

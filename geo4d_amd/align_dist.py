@@ -100,7 +100,11 @@ class AlignShard:
                               "pos": {q: {i: k for k, i in enumerate(v)} for q, v in self.peer_images.items()},
                               "set": {s_: torch.tensor(v, dtype=torch.long, device=dev) for s_, v in self.sets.items()}}
         idx = self._halo_idx
+        # (gloo has no device-tensor send / recv: the CPU tests and the 2-ranks-on-one-GPU rig stage through host memory; RCCL sends device buffers)
+        stage = depth.is_cuda and dist.get_backend(self.group) == "gloo"
         send = {q: depth.index_select(0, idx["peer"][q]).contiguous() for q in self.peers}
+        if stage:
+            send = {q: t.cpu() for q, t in send.items()}
         recv = {q: torch.empty_like(send[q]) for q in self.peers}
         ops = []
         for q in self.peers:
@@ -108,6 +112,8 @@ class AlignShard:
             ops.append(dist.P2POp(dist.irecv, recv[q], self._global_rank(q), self.group))
         for r in dist.batch_isend_irecv(ops):
             r.wait()
+        if stage:
+            recv = {q: t.to(dev) for q, t in recv.items()}
         for s_, imgs in self.sets.items():
             rows = idx["set"][s_]
             total = None
