@@ -179,6 +179,24 @@ def attn_timeline(model, x_T, cond, fs, dev):
     return len(tl), sum(t[0] for t in tl) / 1e12, sum(t[1].elapsed_time(t[2]) for t in tl), sum(t[0] * t[3] for t in tl) / 1e12
 
 
+def clip_leg_vote(cm, dev, world):
+    """The ranks must AGREE that the clip leg succeeded before anything else is exchanged: a rank whose leg raised while its peers
+    sat in one of clip_mode's collectives leaves those peers to the process group's timeout (geo4d_amd.dist: 600 s), after which they raise
+    too; whoever gets here votes, and one failure anywhere marks the leg failed on every rank. `cm` = clip_mode's return value (the record
+    on rank 0, None on the others) or {"error": ...}; returned unchanged unless a peer failed / the communicator is gone."""
+    if world <= 1:
+        return cm
+    failed = isinstance(cm, dict) and "error" in cm
+    try:
+        ok = torch.tensor([0.0 if failed else 1.0], device=dev)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and not failed:
+            cm = {"error": "the clip leg failed on another rank"}
+    except Exception as e:   # noqa: BLE001 - the communicator is gone (a peer timed out): report, do not hang
+        cm = {"error": f"clip leg: ranks could not agree ({type(e).__name__}: {e})"}
+    return cm
+
+
 def synthetic_scene_maps(slices, T, H, W, dev):
     """Decoded maps of a CONSISTENT synthetic scene in the layout run_clip returns ([n_windows, 11, T, H, W]: point map in the
     pc-bbox normalisation, confidence logit, ray directions, ray moments, inverse depth in [-1, 1]) + the per-window camera-to-world
@@ -631,18 +649,10 @@ def main():
         try:
             cm = clip_mode(a2, model, pvae, dev, rank, world)
         except Exception as e:       # noqa: BLE001 - whatever it is, the line still goes out
+            import traceback
+            print(f"[bench rank {rank}] clip leg failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
             cm = {"error": f"{type(e).__name__}: {e}"}
-        if world > 1:
-            # the ranks must AGREE that the leg succeeded before anything else is exchanged: a rank whose leg raised while its
-            # peers sat in one of clip_mode's collectives leaves those peers to the process group's timeout (geo4d_amd.dist: 600 s), after
-            # which they raise too; whoever gets here votes, and one failure anywhere marks the leg failed on every rank
-            try:
-                ok = torch.tensor([0.0 if "error" in cm else 1.0], device=dev)
-                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-                if float(ok.item()) == 0.0 and "error" not in cm:
-                    cm = {"error": "the clip leg failed on another rank"}
-            except Exception as e:   # noqa: BLE001 - the communicator is gone (a peer timed out): report, do not hang
-                cm = {"error": f"clip leg: ranks could not agree ({type(e).__name__}: {e})"}
+        cm = clip_leg_vote(cm, dev, world)
         if rank == 0:
             res["clip_mode"] = cm if "error" in cm else {k: cm[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "scaling", "phase_seconds",
                                                                            "denoised_frames_per_sec", "alignment_outputs_finite", "alignment_vs_scene_truth", "data")} | {

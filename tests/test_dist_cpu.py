@@ -372,6 +372,12 @@ def _bench_clip_worker(rank, world, port, q):
     args = argparse.Namespace(clip_frames=22, height=32, width=64, ddim_steps=2, align_iters=5, clip_align_on_noise=False, dtype="bf16x3", no_graph=False)
     res = bench.clip_mode(args, _StubModel, None, torch.device("cpu"), rank, world,
                           clip_kw=dict(synthesize=_stub_synth, decoder=_stub_decoder, with_cameras=False), align_fn=_stub_align)
+    # the vote main() takes around the leg: clip_mode returns its record on rank 0 and None elsewhere - every rank must reach the all-reduce
+    # (round 6: a `"error" in None` TypeError on rank 1 skipped it and left rank 0 waiting: found on the 2-ranks-on-one-GPU rig)
+    voted = bench.clip_leg_vote(res, torch.device("cpu"), world)
+    assert voted is res
+    peer_failed = bench.clip_leg_vote({"error": "boom"} if rank == 1 else res, torch.device("cpu"), world)
+    assert isinstance(peer_failed, dict) and "error" in peer_failed
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
