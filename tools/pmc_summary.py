@@ -27,7 +27,7 @@ def short(name):
 def klass(n):
     """Kernel class of a short kernel name (the classes of tools/prof_phases.py)."""
     for pre, c in (("conv_gemm_v3", "conv_gemm third generation"), ("conv_gemm_v2", "conv_gemm second generation"), ("conv_gemm_kernel", "conv_gemm first generation"),
-                   ("splitk_reduce", "split-K reduce"), ("gn_", "GroupNorm"), ("ln_kernel", "LayerNorm"), ("flash_attn", "attention"), ("temporal_attn", "attention")):
+                   ("splitk_reduce", "split-K reduce"), ("gn_", "GroupNorm"), ("ln_kernel", "LayerNorm"), ("ln16_kernel", "LayerNorm"), ("flash_attn", "attention"), ("temporal_attn", "attention")):
         if n.startswith(pre):
             return c
     return "other"

@@ -29,7 +29,7 @@ def klass(n):
         return "split-K reduce"
     if n.startswith("gn_"):
         return "GroupNorm"
-    if n.startswith("ln_kernel"):
+    if n.startswith("ln_kernel") or n.startswith("ln16_kernel"):
         return "LayerNorm"
     if n.startswith("flash_attn") or n.startswith("temporal_attn"):
         return "attention"
@@ -38,7 +38,7 @@ def klass(n):
     return "other"
 
 
-OURS = ("conv_gemm", "splitk_reduce", "gn_", "ln_kernel", "flash_attn", "temporal_attn", "softmax_rows", "tokens_from_ncthw", "concat_channels",
+OURS = ("conv_gemm", "splitk_reduce", "gn_", "ln_kernel", "ln16_kernel", "cast_rows_f16", "split_rows_bf16", "flash_attn", "temporal_attn", "softmax_rows", "tokens_from_ncthw", "concat_channels",
         "timestep_embedding", "embed_tokens", "linear_small", "ddim_step", "cfg_combine", "gather_timestep", "advance_index", "ray_", "align_", "adam_",
         "lad_", "select_")
 
