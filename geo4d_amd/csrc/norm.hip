@@ -151,35 +151,40 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* __restrict__ colsum, int blocks_per_stat, int C, int G, float eps,
                                                                float* __restrict__ stats, int nstat, int rows) {
     // one WORKGROUP per (stat, group): a 5-D GroupNorm at level 0 has 32 units of 12800 items each, too few and too long for one
-    // wave per unit (first version: slower than the statistics pass it replaced)
-    __shared__ float red[4][3];
+    // wave per unit (first version: slower than the statistics pass it replaced).
+    // Round 6: the items are raw (sum, sum of squares) pairs, so they are simply ADDED - in fp64, fixed order (strided per thread, xor tree in the
+    // wave, the 4 waves in order) - and mean / variance come from the two totals at the end. (Rounds 4-5 turned every item into (n, mean, M2)
+    // and Chan-merged them: a division per item in a dependent chain for no accuracy - each item's M2 was already q - s * mean in fp32 - and the
+    // kernel ran 7.8 us for a few hundred items.)
+    __shared__ double red[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = blockIdx.x;
     const int stat = unit / G, grp = unit - stat * G;
     const int cpg = C / G;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
+    double s = 0.0, q = 0.0;
     const int total = blocks_per_stat * cpg;
     for (int i = tid; i < total; i += 256) {
         const int rb = i / cpg, c = grp * cpg + (i - rb * cpg);
         const f32x2 sq = *(const f32x2*)(colsum + (((long)stat * blocks_per_stat + rb) * C + c) * 2);
-        const float mb = sq[0] / (float)rows;        // one item = `rows` output rows of one channel (32: first-generation GEMM tiles; the wave tile's rows otherwise)
-        chan_merge(n, mean, m2, (float)rows, mb, fmaxf(sq[1] - sq[0] * mb, 0.f));
+        s += (double)sq[0];
+        q += (double)sq[1];
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const float nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
-        float n0 = n, a0 = mean, q0 = m2, n1 = nb, a1 = mb, q1 = qb;
-        if (lane & o) { n0 = nb; a0 = mb; q0 = qb; n1 = n; a1 = mean; q1 = m2; }
-        chan_merge(n0, a0, q0, n1, a1, q1);
-        n = n0; mean = a0; m2 = q0;
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
     }
-    if (lane == 0) { red[wave][0] = n; red[wave][1] = mean; red[wave][2] = m2; }
+    if (lane == 0) { red[wave][0] = s; red[wave][1] = q; }
     __syncthreads();
     if (tid == 0) {
-        n = red[0][0]; mean = red[0][1]; m2 = red[0][2];
-        for (int w2 = 1; w2 < 4; ++w2) chan_merge(n, mean, m2, red[w2][0], red[w2][1], red[w2][2]);    // fixed order
-        stats[((long)stat * G + grp) * 2 + 0] = mean;
-        stats[((long)stat * G + grp) * 2 + 1] = 1.0f / sqrtf(m2 / n + eps);
+        s = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];      // fixed order
+        q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+        const double n = (double)blocks_per_stat * rows * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((long)stat * G + grp) * 2 + 0] = (float)mean;
+        stats[((long)stat * G + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
