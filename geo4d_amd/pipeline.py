@@ -265,6 +265,7 @@ def run_clip(model, videos_all, context, *, pointmap_vae=None, stride=4, video_l
         if B != 1:
             raise ValueError("sharded decode handles one clip at a time")
         nwin = len(slices)
+        wb = min(wb, -(-nwin // world))          # never more windows per batch than a balanced deal gives a rank (14 windows on 8 ranks: 2)
         per_round = world * wb
         for k in range(0, nwin, per_round):
             mine = [k + rank * wb + j for j in range(wb) if k + rank * wb + j < nwin]
