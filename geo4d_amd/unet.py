@@ -165,7 +165,8 @@ def layer_shapes(add, L, c):
 
 
 PRESPLIT = os.environ.get("GEO4D_X3_PRESPLIT", "1") != "0"
-PRESPLIT_UP = os.environ.get("GEO4D_X3_PRESPLIT_UP", "1") != "0"      # A/B switch of round 6: pre-split pass in front of the Upsample convolutions (U-Net and VAE)
+PRESPLIT_UP = os.environ.get("GEO4D_X3_PRESPLIT_UP", "1") != "0"
+FUSED_CONCAT = os.environ.get("GEO4D_FUSED_CONCAT", "1") != "0"     # the skip concatenations' producers write into the consumer's buffer (no concat_channels launches); 0: A/B      # A/B switch of round 6: pre-split pass in front of the Upsample convolutions (U-Net and VAE)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -448,7 +449,8 @@ class UNetModel(ParamTree):
         return (self.generation, kv[0].data_ptr())
 
     # ---- layer executors (all enqueue HIP kernels; tensors are token matrices [(b t) hw, C]) -------------
-    def _res(self, e, L, h, emb_all, B, T, H, W):
+    def _res(self, e, L, h, emb_all, B, T, H, W, out=None):
+        """`out` (every layer executor): where the layer's LAST launch writes its result - a column view of a wider buffer (FUSED_CONCAT)."""
         F_, HW = B * T, H * W
         sp = self.presplit
         sp3 = "f16" if e.get("x2") else sp           # operand format of the two 3x3 convolutions
@@ -458,13 +460,13 @@ class UNetModel(ParamTree):
                               rowbias_div=T * HW, gn_stats=True)      # gn_stats: the epilogue sums the next GroupNorm's statistics
         a = ops.groupnorm(h1, *e["gn2"], F=F_, HW=HW, eps=1e-5, silu=True, split_out=sp3)
         skip = ops.linear(h, *e["skip"]) if "skip" in e else h
-        h2, _, _ = ops.conv2d(a, e["w2"], e["b2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True)
+        h2, _, _ = ops.conv2d(a, e["w2"], e["b2"], F=F_, Hin=H, Win=W, KH=3, KW=3, pad=1, residual=skip, gn_stats=True, out=None if "tc" in e else out)
         if "tc" in e:
             y = h2
             spt = "f16" if e.get("x2t") else sp
             for i, (gn, w, b) in enumerate(e["tc"]):
                 a = ops.groupnorm(y, *gn, F=F_, HW=HW, eps=1e-5, frames_per_stat=T, silu=True, split_out=spt)
-                y = ops.conv_temporal(a, w, b, B=B, T=T, HW=HW, residual=h2 if i == 3 else None, gn_stats=True)
+                y = ops.conv_temporal(a, w, b, B=B, T=T, HW=HW, residual=h2 if i == 3 else None, gn_stats=True, out=out if i == 3 else None)
             h2 = y
         return h2
 
@@ -474,7 +476,7 @@ class UNetModel(ParamTree):
         g = ops.linear(ops.layernorm(x, *blk["norm3"], split_out=sp), *blk["ff1"], act=2, split_out=sp)
         return ops.linear(g, *blk["ff2"], residual=x)
 
-    def _spatial(self, e, L, h, kv, B, T, H, W):
+    def _spatial(self, e, L, h, kv, B, T, H, W, out=None):
         F_, N, C_, heads = B * T, H * W, L.inner, L.heads
         blk = e["blk"]
         sp = self.presplit
@@ -517,9 +519,9 @@ class UNetModel(ParamTree):
             att = ops.attention(q, sets, B=F_, H=heads, Nq=N, scale=0.125, x3=x3, split_out=sp)
         x = ops.linear(att, *blk["attn2.o"], residual=x)
         x = self._ff(blk, x)
-        return ops.linear(x, *e["out"], residual=h, gn_stats=True)
+        return ops.linear(x, *e["out"], residual=h, gn_stats=True, out=out)
 
-    def _temporal(self, e, L, h, B, T, H, W):
+    def _temporal(self, e, L, h, B, T, H, W, out=None):
         F_, HW, C_, heads = B * T, H * W, L.inner, L.heads
         blk = e["blk"]
         sp = self.presplit
@@ -530,23 +532,29 @@ class UNetModel(ParamTree):
             att = ops.temporal_attention(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B=B, T=T, HW=HW, H=heads, scale=0.125, split_out=False if t16 else sp)
             x = ops.linear(att, *blk[a + ".o"], residual=x)
         x = self._ff(blk, x)
-        return ops.linear(x, *e["out"], residual=h, gn_stats=True)
+        return ops.linear(x, *e["out"], residual=h, gn_stats=True, out=out)
 
-    def _run(self, P, layers, h, emb_all, kv, B, T, H, W):
+    def _run(self, P, layers, h, emb_all, kv, B, T, H, W, out=None):
+        """`out`: a function (rows) -> the [rows, C] view the block's LAST layer writes its result into (or None): the next skip
+        concatenation's buffer, so that torch.cat([h, hs.pop()], 1) (openaimodel3d.py:624-626) never runs as a copy (FUSED_CONCAT)."""
         for L in layers:
             e = P[L.prefix]
+            o = None
+            if out is not None and L is layers[-1]:
+                Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if L.kind == "down" else (2 * H, 2 * W) if L.kind == "up" else (H, W)
+                o = out(B * T * Ho * Wo)
             if L.kind == "res":
-                h = self._res(e, L, h, emb_all, B, T, H, W)
+                h = self._res(e, L, h, emb_all, B, T, H, W, out=o)
             elif L.kind == "spatial":
-                h = self._spatial(e, L, h, kv, B, T, H, W)
+                h = self._spatial(e, L, h, kv, B, T, H, W, out=o)
             elif L.kind == "temporal":
-                h = self._temporal(e, L, h, B, T, H, W)
+                h = self._temporal(e, L, h, B, T, H, W, out=o)
             elif L.kind == "down":
-                h, H, W = ops.conv2d(h, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, stride=2, pad=1, gn_stats=True)
+                h, H, W = ops.conv2d(h, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, stride=2, pad=1, gn_stats=True, out=o)
             elif L.kind == "up":
                 # (bf16x3 modes: the stream is split ONCE by its own pass instead of per K slab and wave inside the conv - same bits, PRESPLIT_UP)
                 a = ops.presplit(h) if (self.presplit and PRESPLIT_UP) else h
-                h, H, W = ops.conv2d(a, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2)
+                h, H, W = ops.conv2d(a, e["w"], e["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, ups=2, out=o)
         return h, H, W
 
     # ---- public forward -------------------------------------------------------------------------------------
@@ -582,18 +590,44 @@ class UNetModel(ParamTree):
         # tokens
         e0 = P[inputs[0][0].prefix]
         h = ops.tokens_from_ncthw(x.float().contiguous(), None if c_concat is None else c_concat.float().contiguous(), e0["cpad"], dt)
-        h, _, _ = ops.conv2d(h, e0["w"], e0["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True)
+        # FUSED_CONCAT (round 6): output block j reads torch.cat([h, hs.pop()], 1). Instead of copying both halves into a new tensor
+        # (concat_channels: 12 launches per forward), both PRODUCERS write straight into that block's buffer: the input block's last launch
+        # into columns [Ch, Ch + Cs) when the skip is made (its result then flows on as a column view: every kernel takes a row pitch), the
+        # previous output block's (or the middle block's) last launch into columns [0, Ch). Same kernels, same operands: same bits.
+        n_in = len(inputs)
+        cats = {}                                             # index of the consuming output block -> its concatenated input buffer
+
+        def half(j, left):
+            """-> function(rows) returning the [rows, C] view of output block j's input that a producer fills."""
+            if not FUSED_CONCAT or j >= len(outputs):
+                return None
+            ccat = outputs[j][0].cin                          # = Ch (incoming h) + Cs (the skip popped for block j)
+
+            def view(rows, j=j, left=left, ccat=ccat):
+                buf = cats.get(j)
+                if buf is None:
+                    buf = cats[j] = torch.empty((rows, ccat), device=x.device, dtype=dt)
+                assert buf.shape[0] == rows, "latent height/width must be multiples of 8"
+                cs = skip_ch[n_in - 1 - j]
+                return buf[:, :ccat - cs] if left else buf[:, ccat - cs:]
+            return view
+        skip_ch = [blk[-1].cout if blk[-1].kind != "temporal" and blk[-1].kind != "spatial" else blk[-1].cin for blk in inputs]
+        o0 = half(n_in - 1, False)
         if init_attn is not None:
-            h = self._temporal(P[init_attn.prefix], init_attn, h, B, T, H, W)
+            h, _, _ = ops.conv2d(h, e0["w"], e0["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True)
+            h = self._temporal(P[init_attn.prefix], init_attn, h, B, T, H, W, out=None if o0 is None else o0(B * T * H * W))
+        else:
+            h, _, _ = ops.conv2d(h, e0["w"], e0["b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, gn_stats=True, out=None if o0 is None else o0(B * T * H * W))
         hs = [(h, H, W)]
-        for blk in inputs[1:]:
-            h, H, W = self._run(P, blk, h, emb_all, kv, B, T, H, W)
+        for i, blk in enumerate(inputs[1:], start=1):
+            h, H, W = self._run(P, blk, h, emb_all, kv, B, T, H, W, out=half(n_in - 1 - i, False))
             hs.append((h, H, W))
-        h, H, W = self._run(P, middle, h, emb_all, kv, B, T, H, W)
-        for blk in outputs:
+        h, H, W = self._run(P, middle, h, emb_all, kv, B, T, H, W, out=half(0, True))
+        for j, blk in enumerate(outputs):
             s, sh, sw = hs.pop()
             assert (sh, sw) == (H, W), "latent height/width must be multiples of 8"
-            h, H, W = self._run(P, blk, ops.concat_channels(h, s), emb_all, kv, B, T, H, W)
+            hc = cats.pop(j) if j in cats else ops.concat_channels(h, s)
+            h, H, W = self._run(P, blk, hc, emb_all, kv, B, T, H, W, out=half(j + 1, True))
         a = ops.groupnorm(h, *P["out_gn"], F=B * T, HW=H * W, eps=1e-5, silu=True, split_out=self.presplit)
         y, _, _ = ops.conv2d(a, P["out_w"], P["out_b"], F=B * T, Hin=H, Win=W, KH=3, KW=3, pad=1, T=T, out_nchw=True,
                              out_dtype=torch.float32)

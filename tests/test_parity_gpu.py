@@ -67,6 +67,29 @@ def test_unet_vs_reference_golden(dev, mode, tol, case):
     assert e < tol
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3m", "bf16"])
+def test_skip_concatenation_written_by_its_producers_is_bit_identical(dev, mode):
+    """Round 6 (unet.FUSED_CONCAT): the last launch of an input block / of the previous output block writes straight into the buffer the
+    output block reads as torch.cat([h, hs.pop()], 1) - no concat_channels copy. Same kernels on the same operands (only row pitches
+    differ): the U-Net output equals the copying path bit for bit, in every storage type, for both golden cases."""
+    import geo4d_amd.unet as gu
+    g = load("unet_tiny.pt")
+    m = build_unet(g["unet_config"], g["shapes"], dev, mode)
+    for case in ("t16_8x8", "b2_t5_8x16"):
+        c = g["cases"][case]
+        args = (torch.cat([c["x"], c["c_concat"]], 1).to(dev), c["t"].to(dev))
+        kw = dict(context=c["context"].to(dev), fs=c["fs"].to(dev))
+        old = gu.FUSED_CONCAT
+        try:
+            gu.FUSED_CONCAT = False
+            ref = m(*args, **kw).clone()
+            gu.FUSED_CONCAT = True
+            out = m(*args, **kw)
+        finally:
+            gu.FUSED_CONCAT = old
+        assert torch.equal(out, ref), f"{mode} {case}: {rel(out, ref):.3e}"
+
+
 def test_unet_full_config_vs_reference_golden(dev, full_engine):
     """The shipped yaml config (1.44 B parameters) against the reference UNetModel's own output (8x8 latents; the 40x64 pin is
     tests/test_fullsize_gpu.py). One shared model instance, every compute mode."""

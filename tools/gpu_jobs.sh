@@ -261,6 +261,24 @@ PY
       done
     fi
     ;;
+  r6l)         # skip concatenations written by their producers (no concat_channels): bit-identical? A/B by environment switch
+    ( time timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x -k "concatenation or unet or ddim_sampler or window_end or full_size_vs_reference" ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+    grep -E "passed|failed|rc=|Error|error|assert" $O/pytest.log | tail -6
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke
+    bl() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    print(sys.argv[2], round(d["value"], 3), "frames/s", {k: round(v, 1) for k, v in d["split_ms_per_step"].items()}, "gemm ms/fwd", round(r["ms_per_unet_forward"], 2))
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+    }
+    for i in 1 2; do
+      GEO4D_FUSED_CONCAT=0 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows --no-shipped-setting > $O/bench_off_$i.json 2> $O/bench_off_$i.err; bl $O/bench_off_$i.json "concat copies run $i:"
+      timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-strict-mode --no-clip-leg --no-batched-windows --no-shipped-setting > $O/bench_on_$i.json 2> $O/bench_on_$i.err; bl $O/bench_on_$i.json "producers write the halves run $i:"
+    done
+    ;;
   r5a)         # first call of round 5: the two-pass f16 GEMM / bf16x3m mode - correct? how much faster per conv? accurate at size over 50 steps? end to end?
     ( time timeout 600 python -m pytest tests/test_f16x2_gpu.py -m gpu -q -x --durations=5 ) > $O/pytest_x2.log 2>&1; echo "pytest rc=$?" >> $O/pytest_x2.log
     grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_x2.log | tail -12
