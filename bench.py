@@ -272,11 +272,19 @@ def clip_mode(args, model, pvae, dev, rank, world, clip_kw=None, align_fn=None):
         if cuda:
             torch.cuda.synchronize()
     wbn = max(1, int(kw.get("window_batch", 1)))
-    # warm-up: tuning, graph capture, allocator - one group of window_batch windows (16 + 4 (wb - 1) frames at stride 4) and, when the clip's
-    # window count leaves a smaller last group, one single window too
-    run_clip(model, video[:, :, :16 + 4 * (wbn - 1)], ctx, **dict(kw, decode="local", gather=False) if world == 1 else kw)
-    if wbn > 1:
-        run_clip(model, video[:, :, :16], ctx, **dict(kw, decode="local", gather=False) if world == 1 else kw)
+    nwin_all = len(window_slices(N, 4, 16))
+    if world > 1:
+        wbn = min(wbn, -(-nwin_all // world))       # run_clip's own cap in the sharded mode (a balanced deal)
+    # warm-up: tuning, graph capture, allocator - one group of every size the timed clip will meet: window_batch windows and, when the rank's window
+    # count leaves a smaller last group, that many (k windows at stride 4 = a clip of 16 + 4 (k - 1) frames, whose duplicated tail window is dropped
+    # by asking for k - 1 strides: window_slices always appends the tail)
+    if world == 1:
+        sizes = sorted(({min(wbn, nwin_all)} | ({nwin_all % wbn} if nwin_all % wbn else set())) - {0}, reverse=True)
+        for k in sizes:
+            frames = 16 + 4 * max(0, k - 2)                       # k >= 2: k - 1 strided windows + the duplicated tail = k windows; k = 1: two single windows
+            run_clip(model, video[:, :, :frames], ctx, **dict(kw, window_batch=k, decode="local", gather=False))
+    else:                                                         # one full round: every rank denoises window_batch windows (a ragged last round's smaller groups are met in the timed run)
+        run_clip(model, video[:, :, :min(N, 16 + 4 * max(0, world * wbn - 2))], ctx, **dict(kw, window_batch=wbn))
     barrier()
     t0 = time.perf_counter()
     out = run_clip(model, video, ctx, **kw)
@@ -406,7 +414,7 @@ def main():
     ap.add_argument("--align-iters", type=int, default=500, help="--clip-frames: Adam iterations of the global alignment (postprocess.n_iter of the shipped config)")
     ap.add_argument("--no-clip-leg", action="store_true", help="skip the end-to-end clip leg the default run appends under `clip_mode` (ONE 64-frame clip: 14 sliding "
                     "windows + decode + cameras + multi-window alignment, strong-scaled over the ranks; ~45 s on one GPU)")
-    ap.add_argument("--window-batch", type=int, default=2, help="clip modes: windows a rank denoises as ONE batch (pipeline.run_clip window_batch; the headline "
+    ap.add_argument("--window-batch", type=int, default=4, help="clip modes: windows a rank denoises as ONE batch (pipeline.run_clip window_batch; the headline "
                     "metric stays one window per step - BASELINE configs[1] - and reports the batched rate beside it as `batched_windows`)")
     ap.add_argument("--no-batched-windows", action="store_true", help="skip the `batched_windows` leg (the headline's work, --window-batch windows per step)")
     ap.add_argument("--clip-leg-frames", type=int, default=64, help="frames of that clip (64 = BASELINE configs[2]'s window structure, 128 = configs[3])")
